@@ -1,0 +1,42 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    rec = {k: g[k] for k in g.files if k != "meta"}
+    rec["meta"] = json.loads(bytes(g["meta"]).decode())
+    return rec
+
+
+@pytest.fixture(params=golden_names())
+def golden(request):
+    rec = load_golden(request.param)
+    rec["name"] = request.param
+    return rec
+
+
+def same_bits(a, b):
+    """Bitwise equality for float scalars/arrays (NaN == NaN, +0 != -0 is NOT enforced)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
