@@ -1,0 +1,155 @@
+/*
+ * pccm.h -- C ABI of libpccm.so, the MI355X (gfx950) engine under open_pcc_metric_amd.
+ *
+ * The reference (aaletov/open-pcc-metric v0.1.2) is pure Python over the open3d wheel and has
+ * no C ABI / FFI of its own; its "operator interface" for this path is the Python object
+ * protocol of open_pcc_metric/cloud_pair.py.  Each entry point below names the reference
+ * interface it stands under (paths relative to the reference checkout).  The Python binding a
+ * maintainer would add is shown in INTEGRATION.md (ctypes, ~40 lines).
+ *
+ * Conventions
+ *   - every function returns PCCM_OK (0) or a negative PCCM_E_* code; the message of the last
+ *     failure on the calling thread is pccm_last_error().  No C++ exception crosses the ABI.
+ *   - point/normal arrays are packed row-major [n][3], dtype PCCM_F32 or PCCM_F64, in host
+ *     memory (on_device = 0) or device memory of the context's GPU (on_device = 1).  The
+ *     library copies what it needs; callers keep ownership of everything they pass in or out.
+ *   - cloud 0 = origin cloud ("A"), cloud 1 = reconstructed cloud ("B")  (cloud_pair.py:54-59).
+ *   - direction PCCM_DIR_LEFT iterates A and searches B (cloud_pair.py:67-72), PCCM_DIR_RIGHT
+ *     iterates B and searches A (cloud_pair.py:73-78), PCCM_DIR_SELF iterates A and searches A
+ *     for the nearest point with a different row index (cloud_pair.py:108-109).
+ *   - a context belongs to one host thread at a time; different contexts may run concurrently.
+ *   - one context drives one GPU.  Multi-GPU = one process (and context) per GPU, each with
+ *     pccm_set_shard(rank, world); the only cross-rank data are the small vectors documented at
+ *     pccm_reduce(), which the host exchanges with an RCCL all-reduce (DESIGN.md section e).
+ */
+#ifndef PCCM_H
+#define PCCM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCCM_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define PCCM_OK 0
+#define PCCM_E_ARG (-1)    /* bad argument (null, size, non-finite or too large coordinates) -> ValueError */
+#define PCCM_E_NODEV (-2)  /* no usable HIP device */
+#define PCCM_E_HIP (-3)    /* HIP runtime error */
+#define PCCM_E_OOM (-4)    /* device or host allocation failed */
+#define PCCM_E_STATE (-5)  /* call order: clouds / normals / nn result not set yet */
+#define PCCM_E_RANGE (-6)  /* row index outside the other cloud's normals: the reference's IndexError
+                              at metric.py:148-152 */
+
+/* dtypes */
+#define PCCM_F32 0
+#define PCCM_F64 1
+
+/* directions */
+#define PCCM_DIR_LEFT 0
+#define PCCM_DIR_RIGHT 1
+#define PCCM_DIR_SELF 2
+
+/* nearest-neighbour engines (all exact; they differ only in speed) */
+#define PCCM_ENGINE_AUTO 0
+#define PCCM_ENGINE_BRUTE 1 /* LDS-tiled fp32 scan + fp64 certification/refine */
+#define PCCM_ENGINE_GRID 2  /* uniform-grid ring search */
+
+/* which normal row the D2 projection uses */
+#define PCCM_NORMAL_ROW 0       /* row i of the other cloud (what the reference does, metric.py:130,148-152) */
+#define PCCM_NORMAL_NEIGHBOUR 1 /* row nn(i) of the other cloud */
+
+/* per-point quantities */
+#define PCCM_METRIC_D1 0   /* EuclideanDistance(point_to_plane=False): squared NN distance, metric.py:175-177 */
+#define PCCM_METRIC_D2 1   /* EuclideanDistance(point_to_plane=True): projection squared, metric.py:179 */
+#define PCCM_METRIC_PROJ 2 /* ErrorVector(point_to_plane=True): signed projection, metric.py:146-153 */
+
+/* kernel classes for pccm_profile_get() */
+#define PCCM_K_INGEST 0
+#define PCCM_K_SCAN 1     /* brute-force fp32 scan (dominant kernel of PCCM_ENGINE_BRUTE) */
+#define PCCM_K_REFINE 2   /* fp64 certification + winner refine */
+#define PCCM_K_FALLBACK 3 /* exact rescan of uncertified queries */
+#define PCCM_K_POINT 4    /* fused gather + error vector + projection */
+#define PCCM_K_REDUCE 5   /* leaf sums / max / min */
+#define PCCM_K_GRID_BUILD 6
+#define PCCM_K_GRID_QUERY 7
+#define PCCM_K_COUNT 8
+
+typedef struct pccm_ctx pccm_ctx;
+
+int pccm_version(void);
+const char *pccm_last_error(void);
+
+/* Number of HIP devices visible to the process (0 and PCCM_OK when there is none). */
+int pccm_device_count(int *n);
+
+/* Create a context on `device`.  `hip_stream` may be NULL (the library creates its own
+ * non-blocking stream) or a hipStream_t the caller owns (e.g. torch's current stream). */
+int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out);
+int pccm_ctx_destroy(pccm_ctx *ctx);
+
+/* Replaces CloudPair.__init__'s capture of the two clouds, cloud_pair.py:54-59.
+ * Coordinates must be finite with |x| <= 1e15.  Invalidates earlier nn results. */
+int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dtype, int on_device);
+
+/* Replaces np.asarray(cloud.normals), metric.py:92-98.  n must equal the cloud's point count
+ * for PCCM_NORMAL_NEIGHBOUR; PCCM_NORMAL_ROW only needs the rows it indexes. */
+int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype, int on_device);
+
+/* Query-axis shard of this context: rank r of `world` owns, in every direction, the rows
+ * [begin, end) of the iterating cloud returned by pccm_shard_range (boundaries are multiples
+ * of 128 rows so that reduction leaves never straddle ranks).  Default: rank 0 of 1. */
+int pccm_set_shard(pccm_ctx *ctx, int rank, int world);
+int pccm_shard_range(pccm_ctx *ctx, int dir, int64_t *begin, int64_t *end);
+
+/* Replaces get_neighbour_cloud(), cloud_pair.py:10-42 (and, for PCCM_DIR_SELF, Open3D's
+ * compute_nearest_neighbor_distance behind cloud_pair.py:108-109): exact 1-NN of every row
+ * of the shard, squared L2 distance d2 = ((dx*dx)+(dy*dy))+(dz*dz) in fp64, exact ties to the
+ * smallest row index.  Asynchronous on the context's stream; results stay on the device. */
+int pccm_nn(pccm_ctx *ctx, int dir, int engine);
+
+/* Copy the shard's results to the host (either pointer may be NULL).  idx[i] is the row in
+ * the searched cloud, d2[i] the squared distance: the (idxs, sqrdists) of cloud_pair.py:32-33
+ * and the value behind get_left/right_neighbour_distances(), cloud_pair.py:102-106. */
+int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2);
+
+/* get_left/right_error_vector(), cloud_pair.py:90-100: out[i][:] = iter[i] - search[nn(i)]. */
+int pccm_error_vectors(pccm_ctx *ctx, int dir, double *out);
+
+/* Per-point metric vector of the shard (PCCM_METRIC_*), metric.py:124-179. */
+int pccm_point_metric(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *out);
+
+/* Fused reduction of a per-point metric over the shard: the np.sum / np.max of
+ * GeoMSE.calculate (metric.py:226-228), GeoHausdorffDistance.calculate (metric.py:366) and
+ * the np.min / np.max of BoundarySqrtDistances (metric.py:187-188; apply sqrt to both).
+ *
+ *   xvec    [pccm_xvec_len(n_iter)] doubles, zero except for this shard's entries:
+ *           first 64 * (n_iter / 8192) sums of aligned 128-row leaves, accumulated exactly as
+ *           NumPy's pairwise sum does, then the (n_iter % 8192) raw values of the last,
+ *           partial 8192-row chunk.  Summing the xvecs of all ranks element-wise (RCCL
+ *           all-reduce; x + 0 is exact) gives the full vector; pccm_finish_sum() then
+ *           returns bit for bit what np.sum of the whole per-point array returns.
+ *   minmax  [2]: min and max over the shard (+inf / -inf for an empty shard).
+ */
+int64_t pccm_xvec_len(int64_t n_iter);
+int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xvec, double *minmax);
+int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum);
+
+/* Wait for everything queued on the context's stream. */
+int pccm_sync(pccm_ctx *ctx);
+
+/* HIP-event timing of kernel classes on the context's stream (for bench.py's roofline). */
+int pccm_profile_enable(pccm_ctx *ctx, int on);
+int pccm_profile_reset(pccm_ctx *ctx);
+int pccm_profile_get(pccm_ctx *ctx, int kernel_class, double *ms_total, int64_t *launches);
+
+/* Bookkeeping of the last pccm_nn() in `dir`: out[0] = queries sent to the exact fallback
+ * rescan, out[1] = ref-axis splits, out[2] = (query, ref) pairs evaluated by the scan. */
+int pccm_nn_stats(pccm_ctx *ctx, int dir, int64_t out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCCM_H */

@@ -1,0 +1,237 @@
+"""ctypes binding of libpccm.so (include/pccm.h) -- the only door to the GPU.
+
+There is no CPU implementation behind this module: if the shared library is missing, or no
+MI355X is visible when an :class:`Engine` is created, it raises.  Build the library with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C open_pcc_metric_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpccm.so")
+
+OK, E_ARG, E_NODEV, E_HIP, E_OOM, E_STATE, E_RANGE = 0, -1, -2, -3, -4, -5, -6
+F32, F64 = 0, 1
+DIR_LEFT, DIR_RIGHT, DIR_SELF = 0, 1, 2
+ENGINES = {"auto": 0, "brute": 1, "grid": 2}
+NORMAL_MODES = {"row": 0, "neighbour": 1}
+METRIC_D1, METRIC_D2, METRIC_PROJ = 0, 1, 2
+KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4, "reduce": 5,
+                  "grid_build": 6, "grid_query": 7}
+
+# every symbol include/pccm.h declares (tests check that the library exports all of them)
+SYMBOLS = (
+    "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy",
+    "pccm_set_cloud", "pccm_set_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_fetch",
+    "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce", "pccm_finish_sum", "pccm_sync",
+    "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
+)
+
+_lib = None
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libpccm.so and declare the prototypes of include/pccm.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} is not built: open_pcc_metric_amd has no CPU fallback. "
+            "Run `make -C open_pcc_metric_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.pccm_version.restype = i32
+    lib.pccm_last_error.restype = ctypes.c_char_p
+    lib.pccm_device_count.argtypes = [ctypes.POINTER(i32)]
+    lib.pccm_ctx_create.argtypes = [i32, vp, ctypes.POINTER(vp)]
+    lib.pccm_ctx_destroy.argtypes = [vp]
+    lib.pccm_set_cloud.argtypes = [vp, i32, vp, i64, i32, i32]
+    lib.pccm_set_normals.argtypes = [vp, i32, vp, i64, i32, i32]
+    lib.pccm_set_shard.argtypes = [vp, i32, i32]
+    lib.pccm_shard_range.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    lib.pccm_nn.argtypes = [vp, i32, i32]
+    lib.pccm_nn_fetch.argtypes = [vp, i32, vp, vp]
+    lib.pccm_error_vectors.argtypes = [vp, i32, vp]
+    lib.pccm_point_metric.argtypes = [vp, i32, i32, i32, vp]
+    lib.pccm_xvec_len.argtypes = [i64]
+    lib.pccm_xvec_len.restype = i64
+    lib.pccm_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.pccm_finish_sum.argtypes = [vp, i64, dp]
+    lib.pccm_sync.argtypes = [vp]
+    lib.pccm_profile_enable.argtypes = [vp, i32]
+    lib.pccm_profile_reset.argtypes = [vp]
+    lib.pccm_profile_get.argtypes = [vp, i32, dp, ctypes.POINTER(i64)]
+    lib.pccm_nn_stats.argtypes = [vp, i32, ctypes.POINTER(i64)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("pccm_last_error", "pccm_xvec_len"):
+            fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc == OK:
+        return
+    msg = load().pccm_last_error().decode("utf-8", "replace")
+    if rc == E_ARG:
+        raise ValueError(msg)
+    if rc == E_RANGE:
+        raise IndexError(msg)
+    if rc == E_OOM:
+        raise MemoryError(msg)
+    raise RuntimeError(f"libpccm error {rc}: {msg}")
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    _check(load().pccm_device_count(ctypes.byref(n)))
+    return int(n.value)
+
+
+def xvec_len(n: int) -> int:
+    return int(load().pccm_xvec_len(int(n)))
+
+
+def finish_sum(xvec: np.ndarray, n: int) -> float:
+    """np.sum of the whole per-point column, from its (all-reduced) exchange vector."""
+    xvec = np.ascontiguousarray(xvec, dtype=np.float64)
+    if xvec.shape[0] != xvec_len(n):
+        raise ValueError("exchange vector has the wrong length")
+    out = ctypes.c_double(0.0)
+    _check(load().pccm_finish_sum(xvec.ctypes.data_as(ctypes.c_void_p), int(n), ctypes.byref(out)))
+    return np.float64(out.value)
+
+
+def _as_rows(a, what: str) -> Tuple[object, int, int, int, object]:
+    """-> (pointer, n, dtype code, on_device, keepalive) for an (N, 3) f32/f64 array or CUDA tensor."""
+    if hasattr(a, "is_cuda") and hasattr(a, "data_ptr"):      # torch tensor
+        import torch
+        if not a.is_cuda:
+            a = a.detach().cpu().numpy()
+        else:
+            if a.dtype not in (torch.float32, torch.float64):
+                a = a.to(torch.float64)
+            a = a.contiguous()
+            if a.dim() != 2 or a.shape[1] != 3:
+                raise ValueError(f"{what} must have shape (N, 3)")
+            torch.cuda.current_stream(a.device).synchronize()
+            return ctypes.c_void_p(a.data_ptr()), int(a.shape[0]), F32 if a.dtype == torch.float32 else F64, 1, a
+    arr = np.asarray(a)
+    if arr.dtype != np.float32:
+        arr = arr.astype(np.float64, copy=False)
+    arr = np.ascontiguousarray(arr)
+    if arr.ndim != 2 or arr.shape[1] != 3:
+        raise ValueError(f"{what} must have shape (N, 3)")
+    return arr.ctypes.data_as(ctypes.c_void_p), int(arr.shape[0]), F32 if arr.dtype == np.float32 else F64, 0, arr
+
+
+class Engine:
+    """One libpccm context = one GPU.  Method names mirror include/pccm.h."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = load()
+        self._ctx = ctypes.c_void_p()
+        _check(self._lib.pccm_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None,
+                                         ctypes.byref(self._ctx)))
+        self.device = int(device)
+        self._n = [0, 0]
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.pccm_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs ---------------------------------------------------------------------------
+    def set_cloud(self, which: int, points) -> None:
+        ptr, n, dt, dev, keep = _as_rows(points, "points")
+        _check(self._lib.pccm_set_cloud(self._ctx, int(which), ptr, n, dt, dev))
+        self._n[which] = n
+
+    def set_normals(self, which: int, normals) -> None:
+        ptr, n, dt, dev, keep = _as_rows(normals, "normals")
+        _check(self._lib.pccm_set_normals(self._ctx, int(which), ptr, n, dt, dev))
+
+    def set_shard(self, rank: int, world: int) -> None:
+        _check(self._lib.pccm_set_shard(self._ctx, int(rank), int(world)))
+
+    def shard_range(self, direction: int) -> Tuple[int, int]:
+        b, e = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self._lib.pccm_shard_range(self._ctx, int(direction), ctypes.byref(b), ctypes.byref(e)))
+        return int(b.value), int(e.value)
+
+    def n_iter(self, direction: int) -> int:
+        return self._n[1] if direction == DIR_RIGHT else self._n[0]
+
+    # -- nearest neighbours -----------------------------------------------------------------
+    def nn(self, direction: int, engine: str = "auto") -> None:
+        _check(self._lib.pccm_nn(self._ctx, int(direction), ENGINES[engine]))
+
+    def fetch_nn(self, direction: int, want_idx: bool = True, want_d2: bool = True):
+        b, e = self.shard_range(direction)
+        idx = np.empty(e - b, dtype=np.int32) if want_idx else None
+        d2 = np.empty(e - b, dtype=np.float64) if want_d2 else None
+        _check(self._lib.pccm_nn_fetch(self._ctx, int(direction),
+                                       idx.ctypes.data_as(ctypes.c_void_p) if want_idx else None,
+                                       d2.ctypes.data_as(ctypes.c_void_p) if want_d2 else None))
+        return idx, d2
+
+    def error_vectors(self, direction: int) -> np.ndarray:
+        b, e = self.shard_range(direction)
+        out = np.empty((e - b, 3), dtype=np.float64)
+        _check(self._lib.pccm_error_vectors(self._ctx, int(direction), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def point_metric(self, direction: int, metric: int, normal_mode: str = "row") -> np.ndarray:
+        b, e = self.shard_range(direction)
+        out = np.empty(e - b, dtype=np.float64)
+        _check(self._lib.pccm_point_metric(self._ctx, int(direction), int(metric), NORMAL_MODES[normal_mode],
+                                           out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def reduce(self, direction: int, metric: int, normal_mode: str = "row"):
+        """-> (xvec, min, max) of this shard; see pccm_reduce() in include/pccm.h."""
+        xvec = np.empty(xvec_len(self.n_iter(direction)), dtype=np.float64)
+        mm = np.empty(2, dtype=np.float64)
+        _check(self._lib.pccm_reduce(self._ctx, int(direction), int(metric), NORMAL_MODES[normal_mode],
+                                     xvec.ctypes.data_as(ctypes.c_void_p), mm.ctypes.data_as(ctypes.c_void_p)))
+        return xvec, mm[0], mm[1]
+
+    finish_sum = staticmethod(finish_sum)
+
+    # -- housekeeping -------------------------------------------------------------------------
+    def sync(self) -> None:
+        _check(self._lib.pccm_sync(self._ctx))
+
+    def profile(self, on: bool) -> None:
+        _check(self._lib.pccm_profile_enable(self._ctx, int(bool(on))))
+
+    def profile_reset(self) -> None:
+        _check(self._lib.pccm_profile_reset(self._ctx))
+
+    def profile_get(self, kernel_class: str) -> Tuple[float, int]:
+        ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+        _check(self._lib.pccm_profile_get(self._ctx, KERNEL_CLASSES[kernel_class], ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def nn_stats(self, direction: int) -> dict:
+        out = (ctypes.c_int64 * 3)()
+        _check(self._lib.pccm_nn_stats(self._ctx, int(direction), out))
+        return {"fallback_queries": int(out[0]), "splits": int(out[1]), "pairs": int(out[2])}

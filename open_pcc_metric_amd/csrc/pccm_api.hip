@@ -1,0 +1,584 @@
+// C ABI of libpccm.so (include/pccm.h): context, ingest, nn dispatch, getters, reductions,
+// profiling.  Host-side only; kernels live in pccm_brute.hip / pccm_grid.hip / pccm_point.hip.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "pccm_internal.h"
+
+namespace pccm {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int ensure(pccm_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes && b.p) return PCCM_OK;
+    if (b.p) {
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+        PCCM_HIP(hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    PCCM_HIP(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return PCCM_OK;
+}
+
+static hipEvent_t take_event(pccm_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(pccm_ctx *c, int k) : ctx(c), cls(k)
+{
+    if (!ctx->prof_on) return;
+    a = take_event(ctx);
+    b = take_event(ctx);
+    if (a) (void)hipEventRecord(a, ctx->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!ctx->prof_on || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->spans.push_back({a, b, cls});
+}
+
+static int collect_spans(pccm_ctx *ctx)
+{
+    if (ctx->spans.empty()) return PCCM_OK;
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &s : ctx->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            ctx->prof_ms[s.cls] += ms;
+            ctx->prof_n[s.cls] += 1;
+        }
+        ctx->event_pool.push_back(s.a);
+        ctx->event_pool.push_back(s.b);
+    }
+    ctx->spans.clear();
+    return PCCM_OK;
+}
+
+static void free_buf(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+static void free_cloud(Cloud &c)
+{
+    if (c.xyz32) (void)hipFree(c.xyz32);
+    if (c.xyz64) (void)hipFree(c.xyz64);
+    if (c.nrm64) (void)hipFree(c.nrm64);
+    c.xyz32 = nullptr;
+    c.xyz64 = nullptr;
+    c.nrm64 = nullptr;
+    c.n = c.n_pad = c.n_nrm = 0;
+}
+
+static void free_nn(NNResult &r)
+{
+    if (r.idx) (void)hipFree(r.idx);
+    if (r.d2) (void)hipFree(r.d2);
+    r.idx = nullptr;
+    r.d2 = nullptr;
+    r.cap = 0;
+    r.valid = false;
+}
+
+static void shard_of(int64_t n, int rank, int world, int64_t *b, int64_t *e)
+{
+    const int64_t units = (n + kLeaf - 1) / kLeaf;
+    int64_t u0 = units * rank / world, u1 = units * (rank + 1) / world;
+    int64_t lo = u0 * kLeaf, hi = u1 * kLeaf;
+    *b = lo < n ? lo : n;
+    *e = hi < n ? hi : n;
+}
+
+static int dir_clouds(pccm_ctx *ctx, int dir, const Cloud **it, const Cloud **se)
+{
+    if (dir == PCCM_DIR_LEFT) { *it = &ctx->cloud[0]; *se = &ctx->cloud[1]; }
+    else if (dir == PCCM_DIR_RIGHT) { *it = &ctx->cloud[1]; *se = &ctx->cloud[0]; }
+    else if (dir == PCCM_DIR_SELF) { *it = &ctx->cloud[0]; *se = &ctx->cloud[0]; }
+    else return fail(PCCM_E_ARG, "bad direction %d", dir);
+    if ((*it)->n <= 0 || (*se)->n <= 0) return fail(PCCM_E_STATE, "clouds are not set");
+    return PCCM_OK;
+}
+
+static int upload(pccm_ctx *ctx, const void *src, size_t bytes, int on_device, const void **dev_src)
+{
+    if (on_device) {
+        *dev_src = src;
+        return PCCM_OK;
+    }
+    int rc = ensure(ctx, ctx->staging, bytes);
+    if (rc) return rc;
+    PCCM_HIP(hipMemcpyAsync(ctx->staging.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev_src = ctx->staging.p;
+    return PCCM_OK;
+}
+
+}  // namespace pccm
+
+using namespace pccm;
+
+#define CHECK_CTX(ctx)                                          \
+    do {                                                        \
+        if (!(ctx)) return fail(PCCM_E_ARG, "null context");    \
+        hipError_t _e = hipSetDevice((ctx)->device);            \
+        if (_e != hipSuccess) return fail(PCCM_E_HIP, "hipSetDevice: %s", hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" {
+
+int pccm_version(void) { return PCCM_VERSION; }
+
+const char *pccm_last_error(void) { return g_err; }
+
+int pccm_device_count(int *n)
+{
+    if (!n) return fail(PCCM_E_ARG, "null pointer");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return PCCM_OK;
+}
+
+int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
+{
+    if (!out) return fail(PCCM_E_ARG, "null pointer");
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) {
+        (void)hipGetLastError();
+        return fail(PCCM_E_NODEV, "no HIP device is visible: libpccm has no CPU path");
+    }
+    if (device < 0 || device >= c) return fail(PCCM_E_ARG, "device %d out of range (0..%d)", device, c - 1);
+    PCCM_HIP(hipSetDevice(device));
+    pccm_ctx *ctx = new (std::nothrow) pccm_ctx();
+    if (!ctx) return fail(PCCM_E_OOM, "host allocation failed");
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(PCCM_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    int rc = ensure(ctx, ctx->counters, 3 * sizeof(uint32_t));
+    if (!rc) rc = ensure(ctx, ctx->stats, 3 * sizeof(unsigned long long));
+    if (rc) {
+        pccm_ctx_destroy(ctx);
+        return rc;
+    }
+    for (int d = 0; d < 3; ++d) ctx->nn[d].nflag_dev = (uint32_t *)ctx->counters.p + d;
+    *out = ctx;
+    return PCCM_OK;
+}
+
+int pccm_ctx_destroy(pccm_ctx *ctx)
+{
+    if (!ctx) return PCCM_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
+    for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
+    DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->flagged, &ctx->flag_thr,
+                      &ctx->val, &ctx->unit, &ctx->stats, &ctx->staging, &ctx->counters};
+    for (DevBuf *b : bufs) free_buf(*b);
+    grid_release(ctx);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PCCM_OK;
+}
+
+int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dtype, int on_device)
+{
+    CHECK_CTX(ctx);
+    if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
+    if (!xyz || n <= 0) return fail(PCCM_E_ARG, "empty cloud (the reference cannot evaluate one either)");
+    if (n > 0x7fffff00LL) return fail(PCCM_E_ARG, "more than 2^31 points per cloud are not supported");
+    if (dtype != PCCM_F32 && dtype != PCCM_F64) return fail(PCCM_E_ARG, "dtype must be PCCM_F32 or PCCM_F64");
+    Cloud &c = ctx->cloud[which];
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    free_cloud(c);
+    for (int d = 0; d < 3; ++d) ctx->nn[d].valid = false;
+    c.version++;
+    const int64_t n_pad = (n + kScanTile - 1) / kScanTile * kScanTile;
+    PCCM_HIP(hipMalloc((void **)&c.xyz32, (size_t)n_pad * 3 * sizeof(float)));
+    PCCM_HIP(hipMalloc((void **)&c.xyz64, (size_t)n * 3 * sizeof(double)));
+    const size_t esz = dtype == PCCM_F32 ? 4 : 8;
+    const void *dsrc = nullptr;
+    int rc = upload(ctx, xyz, (size_t)n * 3 * esz, on_device, &dsrc);
+    if (rc) return rc;
+    unsigned long long *stats = (unsigned long long *)ctx->stats.p;
+    PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    rc = launch_ingest_points(ctx, dsrc, dtype, n, n_pad, c.xyz32, c.xyz64, stats);
+    if (rc) return rc;
+    unsigned long long h[3];
+    PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    double maxabs;
+    memcpy(&maxabs, &h[0], sizeof(double));
+    if (h[2] != 0 || !(maxabs <= kMaxAbsCoord)) {
+        free_cloud(c);
+        return fail(PCCM_E_ARG, "cloud %d has non-finite coordinates or |x| > 1e15", which);
+    }
+    c.n = n;
+    c.n_pad = n_pad;
+    c.maxabs = maxabs;
+    c.exact32 = (h[1] == 0);
+    return PCCM_OK;
+}
+
+int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype, int on_device)
+{
+    CHECK_CTX(ctx);
+    if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
+    if (!nrm || n <= 0) return fail(PCCM_E_ARG, "empty normals");
+    if (dtype != PCCM_F32 && dtype != PCCM_F64) return fail(PCCM_E_ARG, "dtype must be PCCM_F32 or PCCM_F64");
+    Cloud &c = ctx->cloud[which];
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    if (c.nrm64) {
+        PCCM_HIP(hipFree(c.nrm64));
+        c.nrm64 = nullptr;
+        c.n_nrm = 0;
+    }
+    PCCM_HIP(hipMalloc((void **)&c.nrm64, (size_t)n * 3 * sizeof(double)));
+    const size_t esz = dtype == PCCM_F32 ? 4 : 8;
+    const void *dsrc = nullptr;
+    int rc = upload(ctx, nrm, (size_t)n * 3 * esz, on_device, &dsrc);
+    if (rc) return rc;
+    unsigned long long *stats = (unsigned long long *)ctx->stats.p;
+    PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.nrm64, stats);
+    if (rc) return rc;
+    unsigned long long h[3];
+    PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    if (h[2] != 0) {
+        (void)hipFree(c.nrm64);
+        c.nrm64 = nullptr;
+        return fail(PCCM_E_ARG, "normals of cloud %d are not finite", which);
+    }
+    c.n_nrm = n;
+    return PCCM_OK;
+}
+
+int pccm_set_shard(pccm_ctx *ctx, int rank, int world)
+{
+    CHECK_CTX(ctx);
+    if (world < 1 || rank < 0 || rank >= world) return fail(PCCM_E_ARG, "bad shard %d of %d", rank, world);
+    ctx->rank = rank;
+    ctx->world = world;
+    for (int d = 0; d < 3; ++d) ctx->nn[d].valid = false;
+    return PCCM_OK;
+}
+
+int pccm_shard_range(pccm_ctx *ctx, int dir, int64_t *begin, int64_t *end)
+{
+    CHECK_CTX(ctx);
+    if (!begin || !end) return fail(PCCM_E_ARG, "null pointer");
+    const Cloud *it, *se;
+    int rc = dir_clouds(ctx, dir, &it, &se);
+    if (rc) return rc;
+    shard_of(it->n, ctx->rank, ctx->world, begin, end);
+    return PCCM_OK;
+}
+
+int pccm_nn(pccm_ctx *ctx, int dir, int engine)
+{
+    CHECK_CTX(ctx);
+    const Cloud *it, *se;
+    int rc = dir_clouds(ctx, dir, &it, &se);
+    if (rc) return rc;
+    const bool self = dir == PCCM_DIR_SELF;
+    NNResult &res = ctx->nn[dir];
+    res.valid = false;
+    shard_of(it->n, ctx->rank, ctx->world, &res.begin, &res.end);
+    const int64_t ns = res.end - res.begin;
+    if (ns > res.cap) {
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+        free_nn(res);
+        PCCM_HIP(hipMalloc((void **)&res.idx, (size_t)ns * sizeof(int32_t)));
+        PCCM_HIP(hipMalloc((void **)&res.d2, (size_t)ns * sizeof(double)));
+        res.cap = ns;
+    }
+    res.stats[0] = res.stats[1] = res.stats[2] = 0;
+    if (self && it->n < 2) {
+        // Open3D's compute_nearest_neighbor_distance returns zeros for fewer than two points
+        if (ns > 0) {
+            PCCM_HIP(hipMemsetAsync(res.idx, 0xff, (size_t)ns * sizeof(int32_t), ctx->stream));
+            PCCM_HIP(hipMemsetAsync(res.d2, 0, (size_t)ns * sizeof(double), ctx->stream));
+        }
+        PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, sizeof(uint32_t), ctx->stream));
+        res.valid = true;
+        return PCCM_OK;
+    }
+    if (engine == PCCM_ENGINE_AUTO) {
+        const char *e = getenv("PCCM_ENGINE");
+        if (e && !strcmp(e, "brute")) engine = PCCM_ENGINE_BRUTE;
+        else if (e && !strcmp(e, "grid")) engine = PCCM_ENGINE_GRID;
+        else engine = PCCM_ENGINE_BRUTE;
+    }
+    if (engine == PCCM_ENGINE_BRUTE) rc = nn_brute(ctx, *it, *se, self, res);
+    else if (engine == PCCM_ENGINE_GRID) rc = nn_grid(ctx, dir, *it, *se, self, res);
+    else return fail(PCCM_E_ARG, "unknown engine %d", engine);
+    if (rc) return rc;
+    res.valid = true;
+    return PCCM_OK;
+}
+
+static int need_nn(pccm_ctx *ctx, int dir, const Cloud **it, const Cloud **se, NNResult **res)
+{
+    int rc = dir_clouds(ctx, dir, it, se);
+    if (rc) return rc;
+    *res = &ctx->nn[dir];
+    if (!(*res)->valid) return fail(PCCM_E_STATE, "pccm_nn(dir=%d) has not run for the current clouds/shard", dir);
+    return PCCM_OK;
+}
+
+int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
+{
+    CHECK_CTX(ctx);
+    const Cloud *it, *se;
+    NNResult *res;
+    int rc = need_nn(ctx, dir, &it, &se, &res);
+    if (rc) return rc;
+    const int64_t ns = res->end - res->begin;
+    if (ns > 0 && idx) PCCM_HIP(hipMemcpyAsync(idx, res->idx, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ns > 0 && d2) PCCM_HIP(hipMemcpyAsync(d2, res->d2, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    return PCCM_OK;
+}
+
+static int check_normals(const Cloud &se, const NNResult &res, int normal_mode)
+{
+    if (normal_mode != PCCM_NORMAL_ROW && normal_mode != PCCM_NORMAL_NEIGHBOUR)
+        return fail(PCCM_E_ARG, "bad normal mode %d", normal_mode);
+    if (!se.nrm64) return fail(PCCM_E_STATE, "the searched cloud has no normals (pccm_set_normals)");
+    if (normal_mode == PCCM_NORMAL_ROW && res.end > se.n_nrm)
+        return fail(PCCM_E_RANGE, "index %lld is out of bounds for axis 0 with size %lld (row-indexed normals, reference quirk Q1)",
+                    (long long)se.n_nrm, (long long)se.n_nrm);
+    if (normal_mode == PCCM_NORMAL_NEIGHBOUR && se.n_nrm != se.n)
+        return fail(PCCM_E_ARG, "neighbour-indexed normals need one normal per point");
+    return PCCM_OK;
+}
+
+int pccm_error_vectors(pccm_ctx *ctx, int dir, double *out)
+{
+    CHECK_CTX(ctx);
+    if (!out) return fail(PCCM_E_ARG, "null pointer");
+    const Cloud *it, *se;
+    NNResult *res;
+    int rc = need_nn(ctx, dir, &it, &se, &res);
+    if (rc) return rc;
+    const int64_t ns = res->end - res->begin;
+    if (ns <= 0) return PCCM_OK;
+    if ((rc = ensure(ctx, ctx->val, (size_t)ns * 3 * sizeof(double)))) return rc;
+    if ((rc = launch_point_metric(ctx, *it, *se, *res, PCCM_METRIC_D1, PCCM_NORMAL_ROW, nullptr, (double *)ctx->val.p))) return rc;
+    PCCM_HIP(hipMemcpyAsync(out, ctx->val.p, (size_t)ns * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    return PCCM_OK;
+}
+
+// device pointer to the shard's per-point metric (computing it into ctx->val when needed)
+static int metric_on_device(pccm_ctx *ctx, int dir, int metric, int normal_mode, const double **dev, int64_t *ns_out,
+                            const Cloud **it_out, NNResult **res_out)
+{
+    const Cloud *it, *se;
+    NNResult *res;
+    int rc = need_nn(ctx, dir, &it, &se, &res);
+    if (rc) return rc;
+    const int64_t ns = res->end - res->begin;
+    *ns_out = ns;
+    *it_out = it;
+    *res_out = res;
+    if (metric == PCCM_METRIC_D1) {
+        *dev = res->d2;
+        return PCCM_OK;
+    }
+    if (metric != PCCM_METRIC_D2 && metric != PCCM_METRIC_PROJ) return fail(PCCM_E_ARG, "bad metric %d", metric);
+    if (dir == PCCM_DIR_SELF) return fail(PCCM_E_ARG, "point-to-plane is not defined for the self search");
+    if ((rc = check_normals(*se, *res, normal_mode))) return rc;
+    if ((rc = ensure(ctx, ctx->val, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
+    if ((rc = launch_point_metric(ctx, *it, *se, *res, metric, normal_mode, (double *)ctx->val.p, nullptr))) return rc;
+    *dev = (const double *)ctx->val.p;
+    return PCCM_OK;
+}
+
+int pccm_point_metric(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *out)
+{
+    CHECK_CTX(ctx);
+    if (!out) return fail(PCCM_E_ARG, "null pointer");
+    const double *dev;
+    int64_t ns;
+    const Cloud *it;
+    NNResult *res;
+    int rc = metric_on_device(ctx, dir, metric, normal_mode, &dev, &ns, &it, &res);
+    if (rc) return rc;
+    if (ns > 0) PCCM_HIP(hipMemcpyAsync(out, dev, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    return PCCM_OK;
+}
+
+int64_t pccm_xvec_len(int64_t n_iter)
+{
+    if (n_iter <= 0) return 0;
+    return (n_iter / kChunk) * (kChunk / kLeaf) + (n_iter % kChunk);
+}
+
+int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xvec, double *minmax)
+{
+    CHECK_CTX(ctx);
+    if (!xvec || !minmax) return fail(PCCM_E_ARG, "null pointer");
+    const double *dev;
+    int64_t ns;
+    const Cloud *it;
+    NNResult *res;
+    int rc = metric_on_device(ctx, dir, metric, normal_mode, &dev, &ns, &it, &res);
+    if (rc) return rc;
+    const int64_t n = it->n;
+    const int64_t xlen = pccm_xvec_len(n);
+    memset(xvec, 0, (size_t)xlen * sizeof(double));
+    minmax[0] = INFINITY;
+    minmax[1] = -INFINITY;
+    if (ns <= 0) return PCCM_OK;
+    const int64_t nunits = (ns + kLeaf - 1) / kLeaf;
+    if ((rc = ensure(ctx, ctx->unit, (size_t)nunits * 3 * sizeof(double)))) return rc;
+    if ((rc = launch_unit_reduce(ctx, dev, ns, (double *)ctx->unit.p, nunits))) return rc;
+    ctx->host_unit.resize((size_t)nunits * 3);
+    PCCM_HIP(hipMemcpyAsync(ctx->host_unit.data(), ctx->unit.p, (size_t)nunits * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // raw values of the last, partial 8192-row chunk that fall into this shard
+    const int64_t nfull = n / kChunk, full_rows = nfull * kChunk;
+    const int64_t t0 = res->begin > full_rows ? res->begin : full_rows;
+    if (t0 < res->end)
+        PCCM_HIP(hipMemcpyAsync(xvec + nfull * (kChunk / kLeaf) + (t0 - full_rows), dev + (t0 - res->begin),
+                                (size_t)(res->end - t0) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    const double *usum = ctx->host_unit.data(), *umin = usum + nunits, *umax = usum + 2 * nunits;
+    for (int64_t u = 0; u < nunits; ++u) {
+        const int64_t row = res->begin + u * kLeaf;   // shard boundaries are multiples of kLeaf
+        if (row < full_rows) xvec[row / kLeaf] = usum[u];
+        if (umin[u] < minmax[0]) minmax[0] = umin[u];
+        if (umax[u] > minmax[1]) minmax[1] = umax[u];
+    }
+    return PCCM_OK;
+}
+
+static double leaf_tree(const double *l, int cnt)
+{
+    if (cnt == 1) return l[0];
+    return leaf_tree(l, cnt / 2) + leaf_tree(l + cnt / 2, cnt / 2);
+}
+
+int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum)
+{
+    if (!xvec || !sum || n_iter < 0) return fail(PCCM_E_ARG, "bad argument");
+    const int64_t nfull = n_iter / kChunk, tail = n_iter % kChunk;
+    const int lpc = kChunk / kLeaf;
+    double s = 0.0;
+    bool first = true;
+    for (int64_t c = 0; c < nfull; ++c) {
+        double cs = leaf_tree(xvec + c * lpc, lpc);
+        s = first ? cs : s + cs;
+        first = false;
+    }
+    if (tail) {
+        double ts = np_pairwise_sum(xvec + nfull * lpc, tail);
+        s = first ? ts : s + ts;
+    }
+    *sum = s;
+    return PCCM_OK;
+}
+
+int pccm_sync(pccm_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    return PCCM_OK;
+}
+
+int pccm_profile_enable(pccm_ctx *ctx, int on)
+{
+    CHECK_CTX(ctx);
+    int rc = collect_spans(ctx);
+    ctx->prof_on = on != 0;
+    return rc;
+}
+
+int pccm_profile_reset(pccm_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    int rc = collect_spans(ctx);
+    for (int k = 0; k < PCCM_K_COUNT; ++k) {
+        ctx->prof_ms[k] = 0.0;
+        ctx->prof_n[k] = 0;
+    }
+    return rc;
+}
+
+int pccm_profile_get(pccm_ctx *ctx, int kernel_class, double *ms_total, int64_t *launches)
+{
+    CHECK_CTX(ctx);
+    if (kernel_class < 0 || kernel_class >= PCCM_K_COUNT || !ms_total || !launches) return fail(PCCM_E_ARG, "bad argument");
+    int rc = collect_spans(ctx);
+    if (rc) return rc;
+    *ms_total = ctx->prof_ms[kernel_class];
+    *launches = ctx->prof_n[kernel_class];
+    return PCCM_OK;
+}
+
+int pccm_nn_stats(pccm_ctx *ctx, int dir, int64_t out[3])
+{
+    CHECK_CTX(ctx);
+    if (!out) return fail(PCCM_E_ARG, "null pointer");
+    const Cloud *it, *se;
+    NNResult *res;
+    int rc = need_nn(ctx, dir, &it, &se, &res);
+    if (rc) return rc;
+    uint32_t nf = 0;
+    PCCM_HIP(hipMemcpyAsync(&nf, res->nflag_dev, sizeof(nf), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    out[0] = nf;
+    out[1] = res->stats[1];
+    out[2] = res->stats[2];
+    return PCCM_OK;
+}
+
+}  // extern "C"

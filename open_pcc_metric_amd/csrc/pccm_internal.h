@@ -1,0 +1,118 @@
+// Internal declarations shared by the translation units of libpccm.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "pccm.h"
+
+namespace pccm {
+
+// ---- geometry of the brute-force scan (K1) ------------------------------------------
+constexpr int kScanThreads = 256;   // 4 waves of 64
+constexpr int kScanTile = 1024;     // search points staged in LDS per buffer
+constexpr int kTileVec = kScanTile / 4 * 3;   // float4 vectors per tile in the quad layout (12 KB)
+constexpr int kGranule = 64;        // winner tracking granularity = one wave-wide fp64 rescan
+constexpr float kBig32 = 3.0e38f;   // "no candidate" distance (finite: no inf arithmetic in the scan)
+constexpr float kPadCoord = 1.0e18f;  // coordinates of padding points: d2 ~ 3e36, never wins
+constexpr double kMaxAbsCoord = 1.0e15;
+
+// ---- reduction geometry: NumPy's pairwise sum (numpy/_core/src/umath/loops_utils.h.src) --
+constexpr int kLeaf = 128;          // PW_BLOCKSIZE
+constexpr int kChunk = 8192;        // NumPy's default ufunc buffer size in elements
+
+struct Cloud {
+    int64_t n = 0;
+    int64_t n_pad = 0;          // multiple of kScanTile
+    float4 *xyz32 = nullptr;    // [n_pad/4][3] quads: x0..3 | y0..3 | z0..3; padding rows = kPadCoord
+    double *xyz64 = nullptr;    // [n][3]
+    double *nrm64 = nullptr;    // [n_nrm][3]
+    int64_t n_nrm = 0;
+    bool exact32 = true;        // every coordinate survives the fp64 -> fp32 -> fp64 round trip
+    double maxabs = 0.0;
+    uint64_t version = 0;       // bumped by pccm_set_cloud (grid caches key on it)
+};
+
+struct NNResult {
+    bool valid = false;
+    int64_t begin = 0, end = 0; // shard rows of the iterating cloud
+    int32_t *idx = nullptr;     // [end-begin]
+    double *d2 = nullptr;       // [end-begin]
+    int64_t cap = 0;
+    int64_t stats[3] = {0, 0, 0};
+    uint32_t *nflag_dev = nullptr;  // device counter of fallback queries of the last run
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ProfSpan {
+    hipEvent_t a, b;
+    int cls;
+};
+
+}  // namespace pccm
+
+struct pccm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    pccm::Cloud cloud[2];
+    int rank = 0, world = 1;
+    pccm::NNResult nn[3];
+    // scratch
+    pccm::DevBuf part_b1, part_g, part_b2, flagged, flag_thr, val, unit, stats, staging, counters;
+    std::vector<double> host_unit;
+    // profiling
+    bool prof_on = false;
+    std::vector<pccm::ProfSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[PCCM_K_COUNT] = {0};
+    int64_t prof_n[PCCM_K_COUNT] = {0};
+};
+
+namespace pccm {
+
+// error plumbing ---------------------------------------------------------------------
+int fail(int code, const char *fmt, ...);
+#define PCCM_HIP(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return ::pccm::fail(_e == hipErrorOutOfMemory ? PCCM_E_OOM : PCCM_E_HIP, "%s: %s", \
+                                #expr, hipGetErrorString(_e));                                \
+    } while (0)
+
+int ensure(pccm_ctx *ctx, DevBuf &b, size_t bytes);
+
+struct ProfScope {   // records a HIP-event pair around a launch group when profiling is on
+    pccm_ctx *ctx;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(pccm_ctx *c, int k);
+    ~ProfScope();
+};
+
+// kernel launchers (each returns PCCM_OK or an error) -----------------------------------
+int launch_ingest_points(pccm_ctx *ctx, const void *src, int dtype, int64_t n, int64_t n_pad, float4 *x32,
+                         double *x64, unsigned long long *stats /*[3] device*/);
+int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, double *out,
+                          unsigned long long *stats);
+
+// brute-force engine: fills res.idx / res.d2 for rows [res.begin, res.end) of `it` searched in `se`
+int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
+// grid engine
+int nn_grid(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, bool self, NNResult &res);
+void grid_release(pccm_ctx *ctx);
+
+int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,
+                        int normal_mode, double *out_val /*[ns]*/, double *out_err /*[ns][3] or null*/);
+// per-unit (128 rows) sums/min/max of val[0..ns): unit_out = [3][nunits] (sum, min, max)
+int launch_unit_reduce(pccm_ctx *ctx, const double *val, int64_t ns, double *unit_out, int64_t nunits);
+
+double np_pairwise_sum(const double *a, int64_t n);
+
+}  // namespace pccm

@@ -1,0 +1,223 @@
+// Ingest, fused per-point error/projection kernel (K3) and the NumPy-ordered leaf reduction (K5).
+#include "pccm_internal.h"
+
+namespace pccm {
+
+// ------------------------------------------------------------------------------------------
+// Ingest: packed [n][3] f32/f64 rows -> float4 scan copy (padded) + fp64 copy, and three
+// statistics: max |coordinate| (as fp64 bits; non-negative doubles order like uint64), number
+// of coordinates that do not survive fp64 -> fp32 -> fp64, number of non-finite coordinates.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src, int64_t n, int64_t n_pad,
+                                                       float *__restrict__ x32, double *__restrict__ x64,
+                                                       unsigned long long *__restrict__ stats)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long mx = 0;
+    int inexact = 0, bad = 0;
+    if (i < n) {
+        double v[3];
+        float f[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            v[a] = (double)src[3 * i + a];
+            f[a] = (float)v[a];
+            inexact += ((double)f[a] != v[a]) ? 1 : 0;
+            bad += isfinite(v[a]) ? 0 : 1;
+            unsigned long long b = (unsigned long long)__double_as_longlong(fabs(v[a]));
+            mx = b > mx ? b : mx;
+            x64[3 * i + a] = v[a];
+        }
+        float *qd = x32 + (i >> 2) * 12 + (i & 3);
+        qd[0] = f[0];
+        qd[4] = f[1];
+        qd[8] = f[2];
+    } else if (i < n_pad) {
+        float *qd = x32 + (i >> 2) * 12 + (i & 3);
+        qd[0] = qd[4] = qd[8] = kPadCoord;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+        inexact += __shfl_xor(inexact, off);
+        bad += __shfl_xor(bad, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mx) atomicMax(&stats[0], mx);
+        if (inexact) atomicAdd(&stats[1], (unsigned long long)inexact);
+        if (bad) atomicAdd(&stats[2], (unsigned long long)bad);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_ingest_normals(const T *__restrict__ src, int64_t n3,
+                                                        double *__restrict__ out,
+                                                        unsigned long long *__restrict__ stats)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int bad = 0;
+    if (i < n3) {
+        double v = (double)src[i];
+        out[i] = v;
+        bad = isfinite(v) ? 0 : 1;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicAdd(&stats[2], 1ull);
+}
+
+int launch_ingest_points(pccm_ctx *ctx, const void *src, int dtype, int64_t n, int64_t n_pad, float4 *x32,
+                         double *x64, unsigned long long *stats)
+{
+    ProfScope ps(ctx, PCCM_K_INGEST);
+    dim3 grid((unsigned)((n_pad + 255) / 256));
+    if (dtype == PCCM_F32)
+        hipLaunchKernelGGL((k_ingest_points<float>), grid, dim3(256), 0, ctx->stream, (const float *)src, n, n_pad, (float *)x32, x64, stats);
+    else
+        hipLaunchKernelGGL((k_ingest_points<double>), grid, dim3(256), 0, ctx->stream, (const double *)src, n, n_pad, (float *)x32, x64, stats);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, double *out, unsigned long long *stats)
+{
+    ProfScope ps(ctx, PCCM_K_INGEST);
+    const int64_t n3 = 3 * n;
+    dim3 grid((unsigned)((n3 + 255) / 256));
+    if (dtype == PCCM_F32)
+        hipLaunchKernelGGL((k_ingest_normals<float>), grid, dim3(256), 0, ctx->stream, (const float *)src, n3, out, stats);
+    else
+        hipLaunchKernelGGL((k_ingest_normals<double>), grid, dim3(256), 0, ctx->stream, (const double *)src, n3, out, stats);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: gather the matched point, error vector e = iter[i] - search[nn(i)] (cloud_pair.py:90-100),
+// projection on the other cloud's normal (metric.py:146-153) and its square (metric.py:179).
+// The dot product is the FMA chain fma(e2,n2, fma(e1,n1, e0*n0)) that np.dot (OpenBLAS ddot)
+// evaluates on FMA-capable hosts; see oracle/pccm_oracle.c for how that was pinned.
+// HBM/gather bound: 24 (q) + 4 (idx) + 24 (r, gathered) + 24 (normal) + 8 (out) bytes per row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_point_metric(const double *__restrict__ q64, int64_t q_begin, int64_t ns,
+                                                      const double *__restrict__ r64,
+                                                      const int32_t *__restrict__ idx,
+                                                      const double *__restrict__ nrm, int metric, int normal_mode,
+                                                      double *__restrict__ val, double *__restrict__ err)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const int64_t gi = q_begin + i;
+    const int64_t j = idx[i];
+    const double ex = __dsub_rn(q64[3 * gi], r64[3 * j]);
+    const double ey = __dsub_rn(q64[3 * gi + 1], r64[3 * j + 1]);
+    const double ez = __dsub_rn(q64[3 * gi + 2], r64[3 * j + 2]);
+    if (err) {
+        err[3 * i] = ex;
+        err[3 * i + 1] = ey;
+        err[3 * i + 2] = ez;
+    }
+    if (val) {
+        const int64_t k = (normal_mode == PCCM_NORMAL_ROW) ? gi : j;
+        double p = __dmul_rn(ex, nrm[3 * k]);
+        p = __fma_rn(ey, nrm[3 * k + 1], p);
+        p = __fma_rn(ez, nrm[3 * k + 2], p);
+        val[i] = (metric == PCCM_METRIC_PROJ) ? p : __dmul_rn(p, p);
+    }
+}
+
+int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,
+                        int normal_mode, double *out_val, double *out_err)
+{
+    const int64_t ns = res.end - res.begin;
+    if (ns <= 0) return PCCM_OK;
+    ProfScope ps(ctx, PCCM_K_POINT);
+    dim3 grid((unsigned)((ns + 255) / 256));
+    hipLaunchKernelGGL(k_point_metric, grid, dim3(256), 0, ctx->stream, it.xyz64, res.begin, ns, se.xyz64, res.idx,
+                       se.nrm64, metric, normal_mode, out_val, out_err);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: per-unit (128 rows) sum / min / max.  Eight lanes per unit; lane k accumulates rows
+// k, k+8, k+16, ... in order and the eight accumulators are combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) -- exactly NumPy's pairwise-sum leaf, so that the host
+// can finish np.sum's tree bit for bit (pccm_finish_sum).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unit_reduce(const double *__restrict__ val, int64_t ns,
+                                                     double *__restrict__ usum, double *__restrict__ umin,
+                                                     double *__restrict__ umax, int64_t nunits)
+{
+    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int k = threadIdx.x & 7;
+    if (u >= nunits) return;   // whole 8-lane groups leave together
+    const int64_t base = u * kLeaf;
+    const int64_t cnt = (ns - base < kLeaf) ? ns - base : kLeaf;
+    double r = 0.0, mn = INFINITY, mx = -INFINITY;
+    if (cnt == kLeaf) {
+        r = val[base + k];
+        mn = mx = r;
+#pragma unroll
+        for (int j = 1; j < kLeaf / 8; ++j) {
+            double v = val[base + 8 * j + k];
+            r = __dadd_rn(r, v);
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    } else {
+        for (int64_t e = k; e < cnt; e += 8) {   // partial unit: only min/max are used by the host
+            double v = val[base + e];
+            r = __dadd_rn(r, v);
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        r = __dadd_rn(r, __shfl_xor(r, off));
+        mn = fmin(mn, __shfl_xor(mn, off));
+        mx = fmax(mx, __shfl_xor(mx, off));
+    }
+    if (k == 0) {
+        usum[u] = r;
+        umin[u] = mn;
+        umax[u] = mx;
+    }
+}
+
+int launch_unit_reduce(pccm_ctx *ctx, const double *val, int64_t ns, double *unit_out, int64_t nunits)
+{
+    if (nunits <= 0) return PCCM_OK;
+    ProfScope ps(ctx, PCCM_K_REDUCE);
+    dim3 grid((unsigned)((nunits * 8 + 255) / 256));
+    hipLaunchKernelGGL(k_unit_reduce, grid, dim3(256), 0, ctx->stream, val, ns, unit_out, unit_out + nunits,
+                       unit_out + 2 * nunits, nunits);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+// NumPy's DOUBLE pairwise sum over one contiguous run of at most kChunk values.
+double np_pairwise_sum(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= kLeaf) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+}  // namespace pccm
