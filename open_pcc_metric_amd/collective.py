@@ -1,0 +1,56 @@
+"""Cross-rank exchange for the query-axis shard (DESIGN.md section e).
+
+One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on MI355X, "gloo" in
+the CPU tests).  The only data that ever crosses ranks on the hot path are the per-direction
+exchange vectors of ``pccm_reduce`` (<= n/128 + 8191 doubles) and two extrema; full per-point
+columns are all-gathered only when a getter materialises them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Collective:
+    def __init__(self, group=None, enabled: bool = False):
+        self.group = group
+        self.rank, self.world = 0, 1
+        self._dist = None
+        if enabled or group is not None:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("torch.distributed is not initialised")
+            self._dist = dist
+            self.rank = dist.get_rank(group)
+            self.world = dist.get_world_size(group)
+            self._backend = dist.get_backend(group)
+
+    @property
+    def sharded(self) -> bool:
+        return self.world > 1
+
+    def _tensor(self, arr: np.ndarray):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        return t.cuda() if self._backend == "nccl" else t
+
+    def allreduce(self, arr: np.ndarray, op: str = "sum") -> np.ndarray:
+        if not self.sharded:
+            return arr
+        dist = self._dist
+        t = self._tensor(arr)
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op],
+                        group=self.group)
+        return t.cpu().numpy()
+
+    def allgather_rows(self, local: np.ndarray, counts) -> np.ndarray:
+        """Concatenate the ranks' row blocks (rank r contributes counts[r] rows)."""
+        if not self.sharded:
+            return local
+        import torch
+        width = max(counts)
+        pad = np.zeros((width,) + local.shape[1:], dtype=local.dtype)
+        pad[:local.shape[0]] = local
+        t = self._tensor(pad)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(outs, t, group=self.group)
+        return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(outs, counts)], axis=0)

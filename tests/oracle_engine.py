@@ -1,0 +1,111 @@
+"""Test double with the interface of ``open_pcc_metric_amd._native.Engine`` backed by the CPU
+oracle.  TEST INFRASTRUCTURE: lets the host logic (device columns, metric DAG, sharding and the
+cross-rank exchange) run in the CPU-only suite.  The product never constructs it."""
+import numpy as np
+
+from open_pcc_metric_amd import _native as nat
+from oracle import oracle as orc
+
+
+class OracleEngine:
+    def __init__(self, method="auto"):
+        self.pts = [None, None]
+        self.nrm = [None, None]
+        self.rank, self.world = 0, 1
+        self.res = {}
+        self.method = method
+        self.calls = []
+
+    # inputs
+    def set_cloud(self, which, points):
+        p = np.asarray(points, dtype=np.float64)
+        if p.ndim != 2 or p.shape[1] != 3 or p.shape[0] == 0:
+            raise ValueError("empty cloud")
+        self.pts[which] = np.ascontiguousarray(p)
+        self.res.clear()
+
+    def set_normals(self, which, normals):
+        self.nrm[which] = np.ascontiguousarray(np.asarray(normals, dtype=np.float64))
+
+    def set_shard(self, rank, world):
+        self.rank, self.world = rank, world
+        self.res.clear()
+
+    def n_iter(self, d):
+        return self.pts[1 if d == nat.DIR_RIGHT else 0].shape[0]
+
+    def shard_range(self, d):
+        n = self.n_iter(d)
+        units = (n + 127) // 128
+        return min(n, units * self.rank // self.world * 128), min(n, units * (self.rank + 1) // self.world * 128)
+
+    def _clouds(self, d):
+        return {nat.DIR_LEFT: (0, 1), nat.DIR_RIGHT: (1, 0), nat.DIR_SELF: (0, 0)}[d]
+
+    # nn
+    def nn(self, d, engine="auto"):
+        it, se = self._clouds(d)
+        b, e = self.shard_range(d)
+        q = self.pts[it][b:e]
+        self.calls.append(("nn", d))
+        if d == nat.DIR_SELF:
+            if self.pts[0].shape[0] < 2:
+                self.res[d] = (np.full(e - b, -1, np.int64), np.zeros(e - b))
+                return
+            # skip_same_index works on global rows: search with the full cloud, then slice
+            idx, d2 = orc.nn(self.pts[0], self.pts[0], skip_same_index=True, method=self.method)
+            self.res[d] = (idx[b:e], d2[b:e])
+        else:
+            self.res[d] = orc.nn(q, self.pts[se], method=self.method)
+
+    def fetch_nn(self, d, want_idx=True, want_d2=True):
+        idx, d2 = self.res[d]
+        return (idx.astype(np.int32) if want_idx else None), (d2.copy() if want_d2 else None)
+
+    def error_vectors(self, d):
+        it, se = self._clouds(d)
+        b, e = self.shard_range(d)
+        return self.pts[it][b:e] - self.pts[se][self.res[d][0]]
+
+    def point_metric(self, d, metric, normal_mode="row"):
+        it, se = self._clouds(d)
+        b, e = self.shard_range(d)
+        idx, d2 = self.res[d]
+        if metric == nat.METRIC_D1:
+            return d2.copy()
+        nrm = self.nrm[se]
+        if nrm is None:
+            raise RuntimeError("no normals")
+        if normal_mode == "row":
+            if e > nrm.shape[0]:
+                raise IndexError(f"index {nrm.shape[0]} is out of bounds for axis 0 with size {nrm.shape[0]}")
+            rows = nrm[b:e]
+            proj = orc.point_to_plane(self.pts[it][b:e], self.pts[se], idx, np.ascontiguousarray(rows))
+        else:
+            proj = orc.point_to_plane(self.pts[it][b:e], self.pts[se], idx, nrm, normal_index="neighbour")
+        return proj if metric == nat.METRIC_PROJ else np.square(proj)
+
+    def reduce(self, d, metric, normal_mode="row"):
+        col = self.point_metric(d, metric, normal_mode)
+        n = self.n_iter(d)
+        b, e = self.shard_range(d)
+        xvec = np.zeros(nat.xvec_len(n))
+        nfull = n // 8192
+        full_rows = nfull * 8192
+        for row in range(b, min(e, full_rows), 128):
+            xvec[row // 128] = np.sum(col[row - b:row - b + 128])     # one NumPy pairwise leaf
+        t0 = max(b, full_rows)
+        if t0 < e:
+            xvec[nfull * 64 + (t0 - full_rows):nfull * 64 + (e - full_rows)] = col[t0 - b:]
+        mn = np.min(col) if len(col) else np.inf
+        mx = np.max(col) if len(col) else -np.inf
+        self.calls.append(("reduce", d, metric))
+        return xvec, mn, mx
+
+    finish_sum = staticmethod(nat.finish_sum)
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
