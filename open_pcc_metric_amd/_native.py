@@ -48,6 +48,12 @@ def load() -> ctypes.CDLL:
         raise NativeLibraryMissing(
             f"{LIB_PATH} is not built: open_pcc_metric_amd has no CPU fallback. "
             "Run `make -C open_pcc_metric_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
+    # PyTorch ships its own libamdhip64.so.7; loading it first makes libpccm.so bind to that same
+    # runtime (one HIP runtime per process), so torch device tensors and streams can be handed in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     dp = ctypes.POINTER(ctypes.c_double)

@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: two ``gloo`` ranks shard the query axis, exchange the reduction vectors
+with all-reduce and must reproduce the single-process report bit for bit.  The GPU engine is
+replaced by the oracle-backed test double (tests/oracle_engine.py); the exchange, the shard
+arithmetic, pccm_finish_sum and the metric DAG are the product's own code."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["PCCM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PCCM_ROOT"], "tests"))
+from open_pcc_metric_amd.calculator import MetricCalculator
+from open_pcc_metric_amd.cloud_pair import CloudPair
+from open_pcc_metric_amd.options import CalculateOptions, transform_options
+from open_pcc_metric_amd.point_cloud import PointCloud
+from oracle_engine import OracleEngine
+
+dist.init_process_group("gloo")
+n = int(os.environ["PCCM_N"])
+rng = np.random.default_rng(42)
+a = rng.random((n, 3), dtype=np.float32); b = rng.random((n + 37, 3), dtype=np.float32)
+na = rng.standard_normal((n, 3)); nb = rng.standard_normal((n + 37, 3))
+pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], normal_index="neighbour",
+                 group=dist.group.WORLD, _engine=OracleEngine())
+res = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, True))).as_dict()
+col = np.asarray(pair.get_right_neighbour_distances())          # all-gathered column
+ev = np.asarray(pair.get_left_error_vector())
+out = {"rank": dist.get_rank(), "shard": pair._engine.shard_range(0),
+       "rows": [[list(map(str, k)), float(v).hex()] for k, v in res.items()],
+       "col_sum": float(np.sum(col)).hex(), "col_len": len(col), "ev_sum": float(np.sum(ev)).hex()}
+print("RESULT " + json.dumps(out), flush=True)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n", [1000, 20011])
+def test_two_gloo_ranks_match_single_process(tmp_path, n):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from open_pcc_metric_amd.calculator import MetricCalculator
+    from open_pcc_metric_amd.cloud_pair import CloudPair
+    from open_pcc_metric_amd.options import CalculateOptions, transform_options
+    from open_pcc_metric_amd.point_cloud import PointCloud
+    from oracle_engine import OracleEngine
+
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1")
+    port = 29500 + (os.getpid() + n) % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    outs = [json.loads(line.split("RESULT ", 1)[1]) for line in proc.stdout.splitlines() if "RESULT " in line]
+    assert sorted(o["rank"] for o in outs) == [0, 1]
+    assert outs[0]["rows"] == outs[1]["rows"]                      # both ranks hold the full result
+    shards = sorted(tuple(o["shard"]) for o in outs)
+    assert shards[0][0] == 0 and shards[0][1] == shards[1][0] and shards[1][1] == n and shards[0][1] % 128 == 0
+
+    rng = np.random.default_rng(42)
+    a = rng.random((n, 3), dtype=np.float32); b = rng.random((n + 37, 3), dtype=np.float32)
+    na = rng.standard_normal((n, 3)); nb = rng.standard_normal((n + 37, 3))
+    pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], normal_index="neighbour",
+                     _engine=OracleEngine())
+    res = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, True))).as_dict()
+    want = [[list(map(str, k)), float(v).hex()] for k, v in res.items()]
+    assert outs[0]["rows"] == want                                   # bit-identical to one process
+    assert outs[0]["col_len"] == n + 37
+    assert outs[0]["col_sum"] == float(np.sum(np.asarray(pair.get_right_neighbour_distances()))).hex()
+    assert outs[0]["ev_sum"] == float(np.sum(np.asarray(pair.get_left_error_vector()))).hex()
