@@ -137,6 +137,11 @@ int64_t pccm_xvec_len(int64_t n_iter);
 int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xvec, double *minmax);
 int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum);
 
+/* Forget the search structures derived from the clouds (the grid engine's cell-sorted copies,
+ * the analogue of the KD-trees CloudPair.__init__ builds at cloud_pair.py:65), so that the next
+ * pccm_nn() rebuilds them.  bench.py calls it every step: a step pays for its builds. */
+int pccm_drop_caches(pccm_ctx *ctx);
+
 /* Wait for everything queued on the context's stream. */
 int pccm_sync(pccm_ctx *ctx);
 

@@ -28,7 +28,8 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy",
     "pccm_set_cloud", "pccm_set_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_fetch",
-    "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce", "pccm_finish_sum", "pccm_sync",
+    "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce", "pccm_finish_sum", "pccm_drop_caches",
+    "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
 )
 
@@ -75,6 +76,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.pccm_finish_sum.argtypes = [vp, i64, dp]
     lib.pccm_sync.argtypes = [vp]
+    lib.pccm_drop_caches.argtypes = [vp]
     lib.pccm_profile_enable.argtypes = [vp, i32]
     lib.pccm_profile_reset.argtypes = [vp]
     lib.pccm_profile_get.argtypes = [vp, i32, dp, ctypes.POINTER(i64)]
@@ -225,6 +227,9 @@ class Engine:
     # -- housekeeping -------------------------------------------------------------------------
     def sync(self) -> None:
         _check(self._lib.pccm_sync(self._ctx))
+
+    def drop_caches(self) -> None:
+        _check(self._lib.pccm_drop_caches(self._ctx))
 
     def profile(self, on: bool) -> None:
         _check(self._lib.pccm_profile_enable(self._ctx, int(bool(on))))

@@ -207,6 +207,8 @@ class CloudPair:
     def recompute(self) -> None:
         """Run both directional sweeps again on the clouds already resident in HBM
         (cloud_pair.py:67-78 does this once, eagerly, in the constructor) and drop cached results."""
+        if hasattr(self._engine, "drop_caches"):
+            self._engine.drop_caches()            # search structures are rebuilt, like the KD-trees
         self._engine.nn(nat.DIR_LEFT, self.nn_engine)
         self._engine.nn(nat.DIR_RIGHT, self.nn_engine)
         self._self_done = False

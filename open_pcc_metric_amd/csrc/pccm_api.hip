@@ -196,7 +196,7 @@ int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
         ctx->own_stream = true;
     }
     int rc = ensure(ctx, ctx->counters, 3 * sizeof(uint32_t));
-    if (!rc) rc = ensure(ctx, ctx->stats, 3 * sizeof(unsigned long long));
+    if (!rc) rc = ensure(ctx, ctx->stats, 9 * sizeof(unsigned long long));
     if (rc) {
         pccm_ctx_destroy(ctx);
         return rc;
@@ -247,10 +247,11 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     int rc = upload(ctx, xyz, (size_t)n * 3 * esz, on_device, &dsrc);
     if (rc) return rc;
     unsigned long long *stats = (unsigned long long *)ctx->stats.p;
-    PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    PCCM_HIP(hipMemsetAsync(stats, 0, 9 * sizeof(unsigned long long), ctx->stream));
+    PCCM_HIP(hipMemsetAsync(stats + 3, 0xff, 3 * sizeof(unsigned long long), ctx->stream));
     rc = launch_ingest_points(ctx, dsrc, dtype, n, n_pad, c.xyz32, c.xyz64, stats);
     if (rc) return rc;
-    unsigned long long h[3];
+    unsigned long long h[9];
     PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     double maxabs;
@@ -263,6 +264,16 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     c.n_pad = n_pad;
     c.maxabs = maxabs;
     c.exact32 = (h[1] == 0);
+    for (int k = 0; k < 3; ++k) {
+        auto unkey = [](unsigned long long b) {
+            b = (b >> 63) ? (b & 0x7fffffffffffffffull) : ~b;
+            double v;
+            memcpy(&v, &b, sizeof(v));
+            return v;
+        };
+        c.bb_min[k] = unkey(h[3 + k]);
+        c.bb_max[k] = unkey(h[6 + k]);
+    }
     return PCCM_OK;
 }
 
@@ -354,7 +365,7 @@ int pccm_nn(pccm_ctx *ctx, int dir, int engine)
         const char *e = getenv("PCCM_ENGINE");
         if (e && !strcmp(e, "brute")) engine = PCCM_ENGINE_BRUTE;
         else if (e && !strcmp(e, "grid")) engine = PCCM_ENGINE_GRID;
-        else engine = PCCM_ENGINE_BRUTE;
+        else engine = PCCM_ENGINE_GRID;
     }
     if (engine == PCCM_ENGINE_BRUTE) rc = nn_brute(ctx, *it, *se, self, res);
     else if (engine == PCCM_ENGINE_GRID) rc = nn_grid(ctx, dir, *it, *se, self, res);
@@ -524,6 +535,13 @@ int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum)
         s = first ? ts : s + ts;
     }
     *sum = s;
+    return PCCM_OK;
+}
+
+int pccm_drop_caches(pccm_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    grid_invalidate(ctx);
     return PCCM_OK;
 }
 

@@ -335,6 +335,24 @@ static void launch_k1(bool self, dim3 grid, hipStream_t st, const float *q32, in
         hipLaunchKernelGGL((k1_scan<QT, false>), grid, dim3(kScanThreads), 0, st, q32, qb, nq, r32, ntiles, tps, pb1, pg, pb2);
 }
 
+// Exact rescan of the queries listed in ctx->flagged (count on the device in res.nflag_dev).
+int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res)
+{
+    const int64_t nq = res.end - res.begin;
+    ProfScope ps(ctx, PCCM_K_FALLBACK);
+    dim3 grid((unsigned)(nq < 2048 ? nq : 2048));
+    if (self)
+        hipLaunchKernelGGL((k2b_fallback<true>), grid, dim3(256), 0, ctx->stream, (const float *)it.xyz32, it.xyz64, res.begin,
+                           (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)ctx->flagged.p, (const float *)ctx->flag_thr.p,
+                           res.nflag_dev, res.idx, res.d2);
+    else
+        hipLaunchKernelGGL((k2b_fallback<false>), grid, dim3(256), 0, ctx->stream, (const float *)it.xyz32, it.xyz64, res.begin,
+                           (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)ctx->flagged.p, (const float *)ctx->flag_thr.p,
+                           res.nflag_dev, res.idx, res.d2);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
 int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res)
 {
     const int64_t nq = res.end - res.begin;
@@ -389,19 +407,7 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
                                (float *)ctx->flag_thr.p, res.nflag_dev);
     }
     PCCM_HIP(hipGetLastError());
-    {
-        ProfScope ps(ctx, PCCM_K_FALLBACK);
-        dim3 grid((unsigned)(nq < 2048 ? nq : 2048));
-        if (self)
-            hipLaunchKernelGGL((k2b_fallback<true>), grid, dim3(256), 0, ctx->stream, (const float *)it.xyz32, it.xyz64, res.begin,
-                               (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)ctx->flagged.p, (const float *)ctx->flag_thr.p,
-                               res.nflag_dev, res.idx, res.d2);
-        else
-            hipLaunchKernelGGL((k2b_fallback<false>), grid, dim3(256), 0, ctx->stream, (const float *)it.xyz32, it.xyz64, res.begin,
-                               (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)ctx->flagged.p, (const float *)ctx->flag_thr.p,
-                               res.nflag_dev, res.idx, res.d2);
-    }
-    PCCM_HIP(hipGetLastError());
+    if ((rc = launch_fallback(ctx, it, se, self, res))) return rc;
     res.stats[1] = splits;
     res.stats[2] = nq * se.n;
     return PCCM_OK;

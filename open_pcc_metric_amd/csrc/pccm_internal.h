@@ -31,6 +31,7 @@ struct Cloud {
     int64_t n_nrm = 0;
     bool exact32 = true;        // every coordinate survives the fp64 -> fp32 -> fp64 round trip
     double maxabs = 0.0;
+    double bb_min[3] = {0, 0, 0}, bb_max[3] = {0, 0, 0};   // bounding box (fp64 coordinates)
     uint64_t version = 0;       // bumped by pccm_set_cloud (grid caches key on it)
 };
 
@@ -49,6 +50,22 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// Uniform grid over one cloud (grid engine): cells in x-fastest order, points counting-sorted by cell.
+struct GridRec {          // 32 B: fp64 position + original row
+    double x, y, z;
+    int32_t idx, pad;
+};
+
+struct Grid {
+    uint64_t version = 0;          // Cloud::version it was built from (0 = none)
+    int dim[3] = {1, 1, 1};
+    double org[3] = {0, 0, 0};
+    double h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};   // cell edge per axis
+    int64_t ncells = 0, n = 0;
+    DevBuf cell_start;             // uint32 [ncells + 1]
+    DevBuf recs;                   // GridRec [n]
+};
+
 struct ProfSpan {
     hipEvent_t a, b;
     int cls;
@@ -65,6 +82,8 @@ struct pccm_ctx {
     pccm::NNResult nn[3];
     // scratch
     pccm::DevBuf part_b1, part_g, part_b2, flagged, flag_thr, val, unit, stats, staging, counters;
+    pccm::Grid grid[2];
+    pccm::DevBuf g_cell_of, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch
     std::vector<double> host_unit;
     // profiling
     bool prof_on = false;
@@ -107,6 +126,8 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
 // grid engine
 int nn_grid(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, bool self, NNResult &res);
 void grid_release(pccm_ctx *ctx);
+void grid_invalidate(pccm_ctx *ctx);
+int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
 
 int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,
                         int normal_mode, double *out_val /*[ns]*/, double *out_err /*[ns][3] or null*/);

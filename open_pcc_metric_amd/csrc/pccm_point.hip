@@ -5,9 +5,17 @@ namespace pccm {
 
 // ------------------------------------------------------------------------------------------
 // Ingest: packed [n][3] f32/f64 rows -> float4 scan copy (padded) + fp64 copy, and three
-// statistics: max |coordinate| (as fp64 bits; non-negative doubles order like uint64), number
-// of coordinates that do not survive fp64 -> fp32 -> fp64, number of non-finite coordinates.
+// statistics: [0] max |coordinate| (as fp64 bits; non-negative doubles order like uint64), [1] number
+// of coordinates that do not survive fp64 -> fp32 -> fp64, [2] number of non-finite coordinates,
+// [3..5] / [6..8] order keys of the bounding box minimum / maximum per axis (for the grid engine).
 // ------------------------------------------------------------------------------------------
+// monotonic map double -> uint64 (so that atomicMin/atomicMax order like the doubles do)
+__device__ __forceinline__ unsigned long long order_key(double v)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src, int64_t n, int64_t n_pad,
                                                        float *__restrict__ x32, double *__restrict__ x64,
@@ -15,6 +23,7 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long mx = 0;
+    unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};   // bounding box keys
     int inexact = 0, bad = 0;
     if (i < n) {
         double v[3];
@@ -28,6 +37,7 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
             unsigned long long b = (unsigned long long)__double_as_longlong(fabs(v[a]));
             mx = b > mx ? b : mx;
             x64[3 * i + a] = v[a];
+            lo[a] = hi[a] = order_key(v[a]);
         }
         float *qd = x32 + (i >> 2) * 12 + (i & 3);
         qd[0] = f[0];
@@ -43,11 +53,22 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
         mx = o > mx ? o : mx;
         inexact += __shfl_xor(inexact, off);
         bad += __shfl_xor(bad, off);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            unsigned long long l = __shfl_xor(lo[a], off), h = __shfl_xor(hi[a], off);
+            lo[a] = l < lo[a] ? l : lo[a];
+            hi[a] = h > hi[a] ? h : hi[a];
+        }
     }
     if ((threadIdx.x & 63) == 0) {
         if (mx) atomicMax(&stats[0], mx);
         if (inexact) atomicAdd(&stats[1], (unsigned long long)inexact);
         if (bad) atomicAdd(&stats[2], (unsigned long long)bad);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&stats[3 + a], lo[a]);
+            atomicMax(&stats[6 + a], hi[a]);
+        }
     }
 }
 

@@ -32,9 +32,10 @@ def check(na, nb, kind, seed, engine="brute"):
 if __name__ == "__main__":
     print("devices", nat.device_count())
     allok = True
+    ENG = os.environ.get("ENG", "brute")
     for args in [(5, 7, "uniform32", 1), (1000, 1000, "uniform32", 2), (3000, 2500, "f64", 3), (2000, 2000, "lattice", 4),
                  (5000, 4000, "voxel", 5), (70000, 65537, "uniform32", 6)]:
-        allok &= check(*args)
+        allok &= check(*args, engine=ENG)
     print("ALL OK" if allok else "FAILURES")
     # timing
     n = int(os.environ.get("N", 1000000))
@@ -43,9 +44,12 @@ if __name__ == "__main__":
     e = nat.Engine(0); e.set_cloud(0, a); e.set_cloud(1, b)
     e.profile(True)
     for rep in range(2):
-        t = time.perf_counter(); e.nn(0, "brute"); e.sync(); dt = time.perf_counter() - t
+        e.drop_caches()
+        t = time.perf_counter(); e.nn(0, ENG); e.sync(); dt = time.perf_counter() - t
         print(f"nn left {n}x{n}: {dt*1e3:.2f} ms  -> {n*n/dt/1e12*8:.1f} TFLOP/s(8 flop/pair)")
-    for k in ("scan", "refine", "fallback"):
+    for d in (1, 2, 0):
+        t = time.perf_counter(); e.nn(d, ENG); e.sync(); print(f"dir {d} (grids cached): {(time.perf_counter()-t)*1e3:.3f} ms", e.nn_stats(d))
+    for k in ("scan", "refine", "fallback", "grid_build", "grid_query"):
         print(k, e.profile_get(k))
     print(e.nn_stats(0))
     idx, d2 = e.fetch_nn(0)

@@ -15,7 +15,7 @@ from open_pcc_metric_amd.point_cloud import PointCloud
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
-ENGINES = ["brute"]
+ENGINES = ["grid", "brute"]
 
 
 def clouds(kind, na, nb, seed):
@@ -203,7 +203,7 @@ def test_bad_inputs_fail_loudly(engine):
     engine.set_cloud(1, good)
     with pytest.raises(RuntimeError):
         engine.fetch_nn(0)                          # nn has not run for these clouds
-    engine.nn(0, "brute")
+    engine.nn(0, "auto")
     with pytest.raises(RuntimeError):
         engine.point_metric(0, nat.METRIC_D2)       # no normals
 
@@ -214,7 +214,7 @@ def test_device_resident_inputs(engine):
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     engine.set_cloud(0, ta)
     engine.set_cloud(1, tb)
-    engine.nn(1, "brute")
+    engine.nn(1, "auto")
     idx, d2 = engine.fetch_nn(1)
     oi, od = orc.nn(b.astype(np.float64), a.astype(np.float64), method="kdtree")
     assert np.array_equal(idx, oi) and np.array_equal(d2, od)

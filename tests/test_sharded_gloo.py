@@ -53,7 +53,10 @@ def test_two_gloo_ranks_match_single_process(tmp_path, n):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1")
-    port = 29500 + (os.getpid() + n) % 2000
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
