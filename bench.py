@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--engine", default="auto", choices=["auto", "brute", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +98,7 @@ def main():
     n = args.points
     a, b, na, nb = synth(n)
     pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local,
-                     nn_engine=args.engine, group=group)       # H2D + ingest happen here, untimed
+                     nn_engine=args.engine, group=group, use_graph=not args.no_graph)   # H2D + ingest happen here, untimed
     eng = pair._engine
     options = CalculateOptions(color=None, hausdorff=False, point_to_plane=True)
     hd_rows = [("GeoHausdorffDistance", True, False), ("GeoHausdorffDistance", False, False)]
@@ -115,9 +116,9 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3 if not args.no_graph else 0)):   # eager, capture, first replay
         result = step()
-    eng.profile(True)
+    eng.profile(args.no_graph)   # HIP events time eager launches; a hipGraph replay cannot carry them (ROCm 7.2)
     eng.profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -125,6 +126,16 @@ def main():
         result = step()
     fence()
     elapsed = time.perf_counter() - t0
+    prof_leg = "HIP events over the timed region"
+    if not args.no_graph:
+        # kernel durations: the same steps issued eagerly right after the timed region, same process,
+        # same resident data (a kernel runs the same whether a graph or the host launched it)
+        pair._use_graph = False
+        eng.profile(True)
+        eng.profile_reset()
+        for _ in range(min(args.steps, 10)):
+            result = step()
+        prof_leg = f"HIP events over {min(args.steps, 10)} eager steps issued right after the timed hipGraph region"
     eng.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -159,11 +170,12 @@ def main():
     elif gq_n:
         avg_ms = gq_ms / gq_n
         q_rows = (pair._engine.shard_range(0)[1] - pair._engine.shard_range(0)[0])
-        alg_bytes = 16.0 * q_rows + 16.0 * n + 12.0 * q_rows      # sorted query + sorted refs + (idx, d2) out
+        ncells = n / 2.0
+        alg_bytes = 44.0 * q_rows + 32.0 * n + 4.0 * ncells       # query record + (idx, d2) out, search records, cell bounds
         roofline = {"bound": "hbm", "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "traffic": None, "kernel": "grid_query", "avg_launch_ms": round(avg_ms, 4), "launches": gq_n,
-                    "algorithmic_bytes_per_launch": alg_bytes}
+                    "traffic": None, "kernel": "grid_query (k_grid_query_coop + tail kernels)",
+                    "avg_launch_ms": round(avg_ms, 4), "launches": gq_n, "algorithmic_bytes_per_launch": alg_bytes}
 
     line = {
         "metric": "Mpoints/s for symmetric D1+D2 PSNR, N_ref=N_deg=%s" % (f"{n // 1_000_000}M" if n % 1_000_000 == 0 else n),
@@ -172,10 +184,10 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32 scan + f64 refine/reduce", "data": "synthetic",
         "config": {"workload": f"{n} vs {n} uniform-random fp32 xyz + unit normals, symmetric D1+D2 MSE/PSNR + D1 Hausdorff "
                                "(BASELINE.json configs[1]+[2])",
-                   "engine": args.engine, "sharding": f"query-axis x{args.gpus}",
+                   "engine": args.engine, "sharding": f"query-axis x{args.gpus}", "hip_graph": not args.no_graph,
                    "fallback_queries": [s["fallback_queries"] for s in stats],
                    "scan_splits": [s["splits"] for s in stats]},
-        "roofline": roofline,
+        "roofline": roofline, "roofline_measured_by": prof_leg,
         "kernel_ms_total": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
         "result_sample": {"GeoMSE_sym_d1": float(result[("SymmetricMetric", "GeoMSE", True, False, "GeoMSE", False, False)]),
                           "GeoPSNR_sym_d2": float(result[("SymmetricMetric", "GeoPSNR", True, True, "GeoPSNR", False, True)])},

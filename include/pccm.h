@@ -132,8 +132,13 @@ int pccm_point_metric(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
  *           all-reduce; x + 0 is exact) gives the full vector; pccm_finish_sum() then
  *           returns bit for bit what np.sum of the whole per-point array returns.
  *   minmax  [2]: min and max over the shard (+inf / -inf for an empty shard).
+ *
+ * pccm_reduce_prefetch() only enqueues the kernels and the copy of the small result arrays into
+ * pinned host memory (no host wait); a later pccm_reduce() with the same arguments consumes it.
+ * Prefetching every column a report needs right after pccm_nn() makes the host wait once per pair.
  */
 int64_t pccm_xvec_len(int64_t n_iter);
+int pccm_reduce_prefetch(pccm_ctx *ctx, int dir, int metric, int normal_mode);
 int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xvec, double *minmax);
 int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum);
 
@@ -141,6 +146,19 @@ int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum);
  * the analogue of the KD-trees CloudPair.__init__ builds at cloud_pair.py:65), so that the next
  * pccm_nn() rebuilds them.  bench.py calls it every step: a step pays for its builds. */
 int pccm_drop_caches(pccm_ctx *ctx);
+
+/* hipGraph capture.  Between pccm_graph_begin() and pccm_graph_end() only pccm_drop_caches(),
+ * pccm_nn() and pccm_reduce_prefetch() may be called; they are recorded on the context's stream
+ * instead of executed.  The same sequence must have run once before (capture cannot allocate).
+ * pccm_graph_end() instantiates the graph, runs it once and returns its id; pccm_graph_launch()
+ * replays the whole sequence -- kernels and host-side bookkeeping -- with a single launch, after which
+ * pccm_reduce()/pccm_nn_fetch() read the fresh results.  A graph goes stale (PCCM_E_STATE) when
+ * clouds, normals, shard or any buffer it references change.  One report over resident clouds is
+ * ~45 small launches, which an eager host cannot issue as fast as the GPU retires them. */
+int pccm_graph_begin(pccm_ctx *ctx);
+int pccm_graph_end(pccm_ctx *ctx, int *graph_id);
+int pccm_graph_launch(pccm_ctx *ctx, int graph_id);
+int pccm_graph_destroy(pccm_ctx *ctx, int graph_id);
 
 /* Wait for everything queued on the context's stream. */
 int pccm_sync(pccm_ctx *ctx);

@@ -28,7 +28,8 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy",
     "pccm_set_cloud", "pccm_set_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_fetch",
-    "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce", "pccm_finish_sum", "pccm_drop_caches",
+    "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce", "pccm_finish_sum",
+    "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
 )
@@ -74,9 +75,14 @@ def load() -> ctypes.CDLL:
     lib.pccm_xvec_len.argtypes = [i64]
     lib.pccm_xvec_len.restype = i64
     lib.pccm_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.pccm_reduce_prefetch.argtypes = [vp, i32, i32, i32]
     lib.pccm_finish_sum.argtypes = [vp, i64, dp]
     lib.pccm_sync.argtypes = [vp]
     lib.pccm_drop_caches.argtypes = [vp]
+    lib.pccm_graph_begin.argtypes = [vp]
+    lib.pccm_graph_end.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.pccm_graph_launch.argtypes = [vp, i32]
+    lib.pccm_graph_destroy.argtypes = [vp, i32]
     lib.pccm_profile_enable.argtypes = [vp, i32]
     lib.pccm_profile_reset.argtypes = [vp]
     lib.pccm_profile_get.argtypes = [vp, i32, dp, ctypes.POINTER(i64)]
@@ -214,6 +220,10 @@ class Engine:
                                            out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def reduce_prefetch(self, direction: int, metric: int, normal_mode: str = "row") -> None:
+        """Enqueue a reduction without waiting; a later reduce() with the same arguments consumes it."""
+        _check(self._lib.pccm_reduce_prefetch(self._ctx, int(direction), int(metric), NORMAL_MODES[normal_mode]))
+
     def reduce(self, direction: int, metric: int, normal_mode: str = "row"):
         """-> (xvec, min, max) of this shard; see pccm_reduce() in include/pccm.h."""
         xvec = np.empty(xvec_len(self.n_iter(direction)), dtype=np.float64)
@@ -230,6 +240,21 @@ class Engine:
 
     def drop_caches(self) -> None:
         _check(self._lib.pccm_drop_caches(self._ctx))
+
+    # -- hipGraph capture of {drop_caches, nn, reduce_prefetch}* (see include/pccm.h) ----------------
+    def graph_begin(self) -> None:
+        _check(self._lib.pccm_graph_begin(self._ctx))
+
+    def graph_end(self) -> int:
+        gid = ctypes.c_int(-1)
+        _check(self._lib.pccm_graph_end(self._ctx, ctypes.byref(gid)))
+        return int(gid.value)
+
+    def graph_launch(self, graph_id: int) -> None:
+        _check(self._lib.pccm_graph_launch(self._ctx, int(graph_id)))
+
+    def graph_destroy(self, graph_id: int) -> None:
+        _check(self._lib.pccm_graph_destroy(self._ctx, int(graph_id)))
 
     def profile(self, on: bool) -> None:
         _check(self._lib.pccm_profile_enable(self._ctx, int(bool(on))))

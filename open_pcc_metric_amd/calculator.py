@@ -14,7 +14,8 @@ import typing
 import pandas as pd
 
 from .cloud_pair import CloudPair
-from .metric import AbstractMetric, PrimaryMetric, SecondaryMetric, SymmetricMetric
+from .metric import (AbstractMetric, BoundarySqrtDistances, EuclideanDistance, PrimaryMetric, SecondaryMetric,
+                     SymmetricMetric)
 
 _COLUMNS = ("label", "is_left", "point-to-plane", "value")
 
@@ -64,5 +65,28 @@ class MetricCalculator:
         self._calculated_metrics[key] = metric
         return metric
 
+    def _plan(self, metrics_list: typing.List[AbstractMetric]) -> None:
+        """Walk the dependency DAG of the request (no evaluation) and let the CloudPair enqueue every
+        GPU reduction it contains; evaluation below then finds the results already on their way."""
+        prefetch = getattr(self._cloud_pair, "prefetch_reductions", None)
+        if prefetch is None:
+            return
+        wanted, seen, stack = [], set(), list(metrics_list)
+        while stack:
+            m = stack.pop()
+            key = m._key()
+            if key in seen or key in self._calculated_metrics:
+                continue
+            seen.add(key)
+            if isinstance(m, EuclideanDistance):
+                wanted.append((m.is_left, m.point_to_plane))
+            elif isinstance(m, BoundarySqrtDistances):
+                wanted.append("boundary")
+            if isinstance(m, SecondaryMetric):
+                stack.extend(m._get_dependencies().values())
+        if wanted:
+            prefetch(sorted(wanted, key=str))
+
     def calculate(self, metrics_list: typing.List[AbstractMetric]) -> CalculateResult:
+        self._plan(metrics_list)
         return CalculateResult([self._metric_recursive_calculate(m) for m in metrics_list])

@@ -19,7 +19,9 @@ Differences from the reference, all deliberate:
   matched point's normal;
 * exact ties go to the smallest row index (Open3D's order is traversal dependent);
 * ``extent=`` injects ``get_extent()`` (the minimal-OBB is CPU code and not parity-pinned);
-* ``group=`` shards the query axis over the ranks of a ``torch.distributed`` group.
+* ``group=`` shards the query axis over the ranks of a ``torch.distributed`` group;
+* ``use_graph=True`` lets ``recompute()`` replay the whole sweep + reductions of the previous report
+  as one hipGraph launch (for callers that evaluate the same resident pair repeatedly).
 """
 from __future__ import annotations
 
@@ -181,7 +183,7 @@ class CloudPair:
 
     def __init__(self, origin_cloud, reconst_cloud, *, device: typing.Optional[int] = None,
                  nn_engine: str = "auto", normal_index: str = "row", extent=None, group=None,
-                 _engine=None):
+                 use_graph: bool = False, _engine=None):
         if normal_index not in nat.NORMAL_MODES:
             raise ValueError("normal_index must be 'row' or 'neighbour'")
         if nn_engine not in nat.ENGINES:
@@ -189,6 +191,9 @@ class CloudPair:
         self.clouds = (origin_cloud, reconst_cloud)
         self.normal_index = normal_index
         self.nn_engine = nn_engine
+        self._use_graph = bool(use_graph)
+        self._graph_id = None
+        self._last_wanted = None
         self._extent = None if extent is None else np.asarray(extent, dtype=np.float64)
         self._coll = Collective(group)
         if _engine is None:
@@ -207,12 +212,37 @@ class CloudPair:
     def recompute(self) -> None:
         """Run both directional sweeps again on the clouds already resident in HBM
         (cloud_pair.py:67-78 does this once, eagerly, in the constructor) and drop cached results."""
-        if hasattr(self._engine, "drop_caches"):
-            self._engine.drop_caches()            # search structures are rebuilt, like the KD-trees
-        self._engine.nn(nat.DIR_LEFT, self.nn_engine)
-        self._engine.nn(nat.DIR_RIGHT, self.nn_engine)
-        self._self_done = False
+        eng = self._engine
         self._idx_cache = {}
+        if self._use_graph and self._last_wanted is not None and hasattr(eng, "graph_begin"):
+            wants_self = "boundary" in self._last_wanted
+            if self._graph_id is not None:
+                try:
+                    eng.graph_launch(self._graph_id)          # sweeps + the last report's reductions, one launch
+                    self._self_done = wants_self
+                    return
+                except RuntimeError:
+                    self._graph_id = None                     # stale (buffers changed): run eagerly, capture again later
+            else:
+                try:
+                    eng.graph_begin()
+                    self._enqueue_sweeps()
+                    self._self_done = False
+                    self.prefetch_reductions(self._last_wanted, _remember=False)
+                    self._graph_id = eng.graph_end()
+                    self._self_done = wants_self
+                    return
+                except RuntimeError:
+                    self._use_graph = False                   # capture not possible here: stay eager
+        self._enqueue_sweeps()
+        self._self_done = False
+
+    def _enqueue_sweeps(self) -> None:
+        eng = self._engine
+        if hasattr(eng, "drop_caches"):
+            eng.drop_caches()                                 # search structures are rebuilt, like the KD-trees
+        eng.nn(nat.DIR_LEFT, self.nn_engine)
+        eng.nn(nat.DIR_RIGHT, self.nn_engine)
 
     # -- helpers ------------------------------------------------------------------------------
     def _gather(self, direction: int, local: np.ndarray) -> np.ndarray:
@@ -284,6 +314,39 @@ class CloudPair:
 
     def get_right_neighbour_colors(self):
         return np.take(_host_rows(self.clouds[0].colors), self._neighbour_index(nat.DIR_RIGHT), axis=0)
+
+    def prefetch_reductions(self, wanted, _remember: bool = True) -> None:
+        """Enqueue the fused reductions a report is about to ask for, without waiting for any of them.
+
+        ``wanted``: iterable of ``(is_left, point_to_plane)`` pairs and/or the string ``"boundary"``.
+        MetricCalculator.calculate() calls this after walking the DAG of the requested metrics, so
+        that the host waits for the GPU once per report instead of once per column.  Purely an
+        optimisation: columns that were not prefetched are reduced on demand."""
+        eng = self._engine
+        if not hasattr(eng, "reduce_prefetch"):
+            return
+        wanted = list(wanted)
+        if _remember:
+            if self._last_wanted is not None and wanted != self._last_wanted and self._graph_id is not None:
+                eng.graph_destroy(self._graph_id)             # a different report: capture anew next time
+                self._graph_id = None
+            self._last_wanted = wanted
+        for item in wanted:
+            if item == "boundary":
+                if not self._self_done:
+                    eng.nn(nat.DIR_SELF, self.nn_engine)
+                    self._self_done = True
+                eng.reduce_prefetch(nat.DIR_SELF, nat.METRIC_D1, self.normal_index)
+                continue
+            is_left, p2p = item
+            direction = nat.DIR_LEFT if is_left else nat.DIR_RIGHT
+            if not p2p:
+                eng.reduce_prefetch(direction, nat.METRIC_D1, self.normal_index)
+            elif _has_normals(self.clouds[1 if is_left else 0]):
+                try:
+                    eng.reduce_prefetch(direction, nat.METRIC_D2, self.normal_index)
+                except IndexError:
+                    pass          # row-indexed normals out of range: surfaces where the reference raises
 
     # -- fused projection used by metric.ErrorVector ------------------------------------------------
     def point_to_plane_column(self, is_left: bool) -> DeviceColumn:

@@ -25,6 +25,11 @@ int fail(int code, const char *fmt, ...)
 int ensure(pccm_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.bytes && b.p) return PCCM_OK;
+    if (ctx->capturing) {
+        ctx->capture_failed = true;
+        return fail(PCCM_E_STATE, "a buffer must grow during graph capture: run the same call sequence once before capturing");
+    }
+    ctx->epoch++;
     if (b.p) {
         PCCM_HIP(hipStreamSynchronize(ctx->stream));
         PCCM_HIP(hipFree(b.p));
@@ -51,7 +56,9 @@ static hipEvent_t take_event(pccm_ctx *ctx)
 
 ProfScope::ProfScope(pccm_ctx *c, int k) : ctx(c), cls(k)
 {
-    if (!ctx->prof_on) return;
+    // not while capturing: on ROCm 7.2 event-record nodes replayed by a hipGraph return meaningless
+    // (negative) elapsed times, so kernels are timed in eager launches only
+    if (!ctx->prof_on || ctx->capturing) return;
     a = take_event(ctx);
     b = take_event(ctx);
     if (a) (void)hipEventRecord(a, ctx->stream);
@@ -59,7 +66,7 @@ ProfScope::ProfScope(pccm_ctx *c, int k) : ctx(c), cls(k)
 
 ProfScope::~ProfScope()
 {
-    if (!ctx->prof_on || !a || !b) return;
+    if (!ctx->prof_on || ctx->capturing || !a || !b) return;
     (void)hipEventRecord(b, ctx->stream);
     ctx->spans.push_back({a, b, cls});
 }
@@ -152,6 +159,16 @@ using namespace pccm;
         if (_e != hipSuccess) return fail(PCCM_E_HIP, "hipSetDevice: %s", hipGetErrorString(_e)); \
     } while (0)
 
+static void graph_free(GraphRec &g);
+
+#define NOT_CAPTURING(ctx)                                                                          \
+    do {                                                                                           \
+        if ((ctx)->capturing) {                                                                    \
+            (ctx)->capture_failed = true;                                                          \
+            return fail(PCCM_E_STATE, "%s is not allowed between pccm_graph_begin and pccm_graph_end", __func__); \
+        }                                                                                          \
+    } while (0)
+
 extern "C" {
 
 int pccm_version(void) { return PCCM_VERSION; }
@@ -221,6 +238,13 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->flagged, &ctx->flag_thr,
                       &ctx->val, &ctx->unit, &ctx->stats, &ctx->staging, &ctx->counters};
     for (DevBuf *b : bufs) free_buf(*b);
+    for (auto &g : ctx->graphs) graph_free(g);
+    for (auto &s : ctx->slots) {
+        free_buf(s.val);
+        free_buf(s.unit);
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.ev) (void)hipEventDestroy(s.ev);
+    }
     grid_release(ctx);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -230,6 +254,7 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
 int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dtype, int on_device)
 {
     CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
     if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
     if (!xyz || n <= 0) return fail(PCCM_E_ARG, "empty cloud (the reference cannot evaluate one either)");
     if (n > 0x7fffff00LL) return fail(PCCM_E_ARG, "more than 2^31 points per cloud are not supported");
@@ -237,7 +262,8 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     Cloud &c = ctx->cloud[which];
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     free_cloud(c);
-    for (int d = 0; d < 3; ++d) ctx->nn[d].valid = false;
+    for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
+    ctx->epoch++;
     c.version++;
     const int64_t n_pad = (n + kScanTile - 1) / kScanTile * kScanTile;
     PCCM_HIP(hipMalloc((void **)&c.xyz32, (size_t)n_pad * 3 * sizeof(float)));
@@ -280,11 +306,14 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
 int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype, int on_device)
 {
     CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
     if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
     if (!nrm || n <= 0) return fail(PCCM_E_ARG, "empty normals");
     if (dtype != PCCM_F32 && dtype != PCCM_F64) return fail(PCCM_E_ARG, "dtype must be PCCM_F32 or PCCM_F64");
     Cloud &c = ctx->cloud[which];
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int d = 0; d < 3; ++d) ctx->nn_gen[d]++;      // pending D2 reductions used the old normals
+    ctx->epoch++;
     if (c.nrm64) {
         PCCM_HIP(hipFree(c.nrm64));
         c.nrm64 = nullptr;
@@ -314,10 +343,12 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
 int pccm_set_shard(pccm_ctx *ctx, int rank, int world)
 {
     CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
     if (world < 1 || rank < 0 || rank >= world) return fail(PCCM_E_ARG, "bad shard %d of %d", rank, world);
     ctx->rank = rank;
     ctx->world = world;
-    for (int d = 0; d < 3; ++d) ctx->nn[d].valid = false;
+    ctx->epoch++;
+    for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
     return PCCM_OK;
 }
 
@@ -341,9 +372,21 @@ int pccm_nn(pccm_ctx *ctx, int dir, int engine)
     const bool self = dir == PCCM_DIR_SELF;
     NNResult &res = ctx->nn[dir];
     res.valid = false;
+    ctx->nn_gen[dir]++;
     shard_of(it->n, ctx->rank, ctx->world, &res.begin, &res.end);
     const int64_t ns = res.end - res.begin;
+    if (ctx->capturing) {
+        GraphOp op;
+        op.kind = 1;
+        op.dir = dir;
+        ctx->cap_ops.push_back(op);
+    }
     if (ns > res.cap) {
+        if (ctx->capturing) {
+            ctx->capture_failed = true;
+            return fail(PCCM_E_STATE, "result buffers must grow during graph capture: run pccm_nn once before capturing");
+        }
+        ctx->epoch++;
         PCCM_HIP(hipStreamSynchronize(ctx->stream));
         free_nn(res);
         PCCM_HIP(hipMalloc((void **)&res.idx, (size_t)ns * sizeof(int32_t)));
@@ -387,6 +430,7 @@ static int need_nn(pccm_ctx *ctx, int dir, const Cloud **it, const Cloud **se, N
 int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
 {
     CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
     const Cloud *it, *se;
     NNResult *res;
     int rc = need_nn(ctx, dir, &it, &se, &res);
@@ -414,6 +458,7 @@ static int check_normals(const Cloud &se, const NNResult &res, int normal_mode)
 int pccm_error_vectors(pccm_ctx *ctx, int dir, double *out)
 {
     CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
     if (!out) return fail(PCCM_E_ARG, "null pointer");
     const Cloud *it, *se;
     NNResult *res;
@@ -430,8 +475,9 @@ int pccm_error_vectors(pccm_ctx *ctx, int dir, double *out)
 
 // device pointer to the shard's per-point metric (computing it into ctx->val when needed)
 static int metric_on_device(pccm_ctx *ctx, int dir, int metric, int normal_mode, const double **dev, int64_t *ns_out,
-                            const Cloud **it_out, NNResult **res_out)
+                            const Cloud **it_out, NNResult **res_out, DevBuf *valbuf = nullptr)
 {
+    DevBuf &vb = valbuf ? *valbuf : ctx->val;
     const Cloud *it, *se;
     NNResult *res;
     int rc = need_nn(ctx, dir, &it, &se, &res);
@@ -447,15 +493,16 @@ static int metric_on_device(pccm_ctx *ctx, int dir, int metric, int normal_mode,
     if (metric != PCCM_METRIC_D2 && metric != PCCM_METRIC_PROJ) return fail(PCCM_E_ARG, "bad metric %d", metric);
     if (dir == PCCM_DIR_SELF) return fail(PCCM_E_ARG, "point-to-plane is not defined for the self search");
     if ((rc = check_normals(*se, *res, normal_mode))) return rc;
-    if ((rc = ensure(ctx, ctx->val, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
-    if ((rc = launch_point_metric(ctx, *it, *se, *res, metric, normal_mode, (double *)ctx->val.p, nullptr))) return rc;
-    *dev = (const double *)ctx->val.p;
+    if ((rc = ensure(ctx, vb, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
+    if ((rc = launch_point_metric(ctx, *it, *se, *res, metric, normal_mode, (double *)vb.p, nullptr))) return rc;
+    *dev = (const double *)vb.p;
     return PCCM_OK;
 }
 
 int pccm_point_metric(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *out)
 {
     CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
     if (!out) return fail(PCCM_E_ARG, "null pointer");
     const double *dev;
     int64_t ns;
@@ -474,41 +521,119 @@ int64_t pccm_xvec_len(int64_t n_iter)
     return (n_iter / kChunk) * (kChunk / kLeaf) + (n_iter % kChunk);
 }
 
-int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xvec, double *minmax)
+// ---- reductions: enqueue (prefetch) and consume ---------------------------------------------------------
+// A reduction is enqueued into a slot: point kernel (D2/PROJ) -> per-unit sums/min/max -> async copy of
+// the unit arrays and of the shard's raw tail values into pinned host memory -> event.  pccm_reduce()
+// consumes a slot (enqueuing it first when nobody prefetched it), so a caller that prefetches every
+// column it will need waits for the GPU once per step instead of once per column.
+static int slot_enqueue(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int normal_mode)
 {
-    CHECK_CTX(ctx);
-    if (!xvec || !minmax) return fail(PCCM_E_ARG, "null pointer");
     const double *dev;
     int64_t ns;
     const Cloud *it;
     NNResult *res;
-    int rc = metric_on_device(ctx, dir, metric, normal_mode, &dev, &ns, &it, &res);
+    int rc = metric_on_device(ctx, dir, metric, normal_mode, &dev, &ns, &it, &res, &s.val);
     if (rc) return rc;
-    const int64_t n = it->n;
+    s.dir = dir; s.metric = metric; s.mode = normal_mode;
+    s.gen = ctx->nn_gen[dir];
+    s.n_iter = it->n; s.begin = res->begin; s.end = res->end;
+    s.nunits = ns > 0 ? (ns + kLeaf - 1) / kLeaf : 0;
+    const int64_t nfull = it->n / kChunk, full_rows = nfull * kChunk;
+    s.t0 = res->begin > full_rows ? res->begin : full_rows;
+    s.tail_n = s.t0 < res->end ? res->end - s.t0 : 0;
+    const size_t need = (size_t)(3 * s.nunits + s.tail_n + 1) * sizeof(double);
+    if (ctx->capturing && (need > s.host_cap || !s.ev)) {
+        ctx->capture_failed = true;
+        return fail(PCCM_E_STATE, "a reduction slot must be allocated during graph capture: run the sequence once first");
+    }
+    if (need > s.host_cap) {
+        ctx->epoch++;
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = nullptr; s.host_cap = 0;
+        PCCM_HIP(hipHostMalloc((void **)&s.host, need, hipHostMallocDefault));
+        s.host_cap = need;
+    }
+    if (!s.ev) PCCM_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    if (s.nunits > 0) {
+        if ((rc = ensure(ctx, s.unit, (size_t)s.nunits * 3 * sizeof(double)))) return rc;
+        if ((rc = launch_unit_reduce(ctx, dev, ns, (double *)s.unit.p, s.nunits))) return rc;
+        PCCM_HIP(hipMemcpyAsync(s.host, s.unit.p, (size_t)s.nunits * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (s.tail_n > 0)
+            PCCM_HIP(hipMemcpyAsync(s.host + 3 * s.nunits, dev + (s.t0 - res->begin), (size_t)s.tail_n * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (ctx->capturing) {
+        GraphOp op;
+        op.kind = 2;
+        op.dir = dir;
+        op.slot = (int)(&s - ctx->slots);
+        op.snap = s;
+        ctx->cap_ops.push_back(op);
+    } else {
+        PCCM_HIP(hipEventRecord(s.ev, ctx->stream));
+    }
+    s.pending = true;
+    return PCCM_OK;
+}
+
+static ReduceSlot *slot_find(pccm_ctx *ctx, int dir, int metric, int normal_mode)
+{
+    for (auto &s : ctx->slots)
+        if (s.pending && s.dir == dir && s.metric == metric && (metric == PCCM_METRIC_D1 || s.mode == normal_mode) &&
+            s.gen == ctx->nn_gen[dir])
+            return &s;
+    return nullptr;
+}
+
+static ReduceSlot *slot_free(pccm_ctx *ctx)
+{
+    for (auto &s : ctx->slots)
+        if (!s.pending || s.gen != ctx->nn_gen[s.dir]) return &s;
+    return &ctx->slots[0];
+}
+
+int pccm_reduce_prefetch(pccm_ctx *ctx, int dir, int metric, int normal_mode)
+{
+    CHECK_CTX(ctx);
+    if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
+    if (slot_find(ctx, dir, metric, normal_mode)) return PCCM_OK;
+    ReduceSlot *s = slot_free(ctx);
+    if (s->pending && !ctx->capturing) PCCM_HIP(hipEventSynchronize(s->ev));
+    s->pending = false;
+    return slot_enqueue(ctx, *s, dir, metric, normal_mode);
+}
+
+int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xvec, double *minmax)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (!xvec || !minmax) return fail(PCCM_E_ARG, "null pointer");
+    if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
+    ReduceSlot *s = slot_find(ctx, dir, metric, normal_mode);
+    if (!s) {
+        int rc = pccm_reduce_prefetch(ctx, dir, metric, normal_mode);
+        if (rc) return rc;
+        s = slot_find(ctx, dir, metric, normal_mode);
+        if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
+    }
+    PCCM_HIP(hipEventSynchronize(s->ev));
+    s->pending = false;
+    const int64_t n = s->n_iter;
     const int64_t xlen = pccm_xvec_len(n);
     memset(xvec, 0, (size_t)xlen * sizeof(double));
     minmax[0] = INFINITY;
     minmax[1] = -INFINITY;
-    if (ns <= 0) return PCCM_OK;
-    const int64_t nunits = (ns + kLeaf - 1) / kLeaf;
-    if ((rc = ensure(ctx, ctx->unit, (size_t)nunits * 3 * sizeof(double)))) return rc;
-    if ((rc = launch_unit_reduce(ctx, dev, ns, (double *)ctx->unit.p, nunits))) return rc;
-    ctx->host_unit.resize((size_t)nunits * 3);
-    PCCM_HIP(hipMemcpyAsync(ctx->host_unit.data(), ctx->unit.p, (size_t)nunits * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    // raw values of the last, partial 8192-row chunk that fall into this shard
+    const int64_t nunits = s->nunits;
     const int64_t nfull = n / kChunk, full_rows = nfull * kChunk;
-    const int64_t t0 = res->begin > full_rows ? res->begin : full_rows;
-    if (t0 < res->end)
-        PCCM_HIP(hipMemcpyAsync(xvec + nfull * (kChunk / kLeaf) + (t0 - full_rows), dev + (t0 - res->begin),
-                                (size_t)(res->end - t0) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    const double *usum = ctx->host_unit.data(), *umin = usum + nunits, *umax = usum + 2 * nunits;
+    const double *usum = s->host, *umin = usum + nunits, *umax = usum + 2 * nunits;
     for (int64_t u = 0; u < nunits; ++u) {
-        const int64_t row = res->begin + u * kLeaf;   // shard boundaries are multiples of kLeaf
+        const int64_t row = s->begin + u * kLeaf;    // shard boundaries are multiples of kLeaf
         if (row < full_rows) xvec[row / kLeaf] = usum[u];
         if (umin[u] < minmax[0]) minmax[0] = umin[u];
         if (umax[u] > minmax[1]) minmax[1] = umax[u];
     }
+    if (s->tail_n > 0)   // raw values of the last, partial 8192-row chunk that fall into this shard
+        memcpy(xvec + nfull * (kChunk / kLeaf) + (s->t0 - full_rows), s->host + 3 * nunits, (size_t)s->tail_n * sizeof(double));
     return PCCM_OK;
 }
 
@@ -541,13 +666,135 @@ int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum)
 int pccm_drop_caches(pccm_ctx *ctx)
 {
     CHECK_CTX(ctx);
+    if (ctx->capturing) {
+        GraphOp op;
+        op.kind = 0;
+        ctx->cap_ops.push_back(op);
+    }
     grid_invalidate(ctx);
+    return PCCM_OK;
+}
+
+// ---- hipGraph capture of a call sequence ------------------------------------------------------------------
+// A report over resident clouds is ~45 small launches; issued eagerly the host cannot feed the GPU fast
+// enough (MI355X_MICROARCH.md: ~3.5 us per launch).  pccm_graph_begin/end capture the sequence
+// {pccm_drop_caches, pccm_nn, pccm_reduce_prefetch}* on the context's stream into a hipGraph;
+// pccm_graph_launch replays it with one launch and re-applies the host-side bookkeeping of every call.
+static void graph_free(GraphRec &g)
+{
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g.exec = nullptr;
+    g.graph = nullptr;
+    g.valid = false;
+    g.ops.clear();
+}
+
+static int graph_replay(pccm_ctx *ctx, GraphRec &g)
+{
+
+    for (auto &op : g.ops) {
+        if (op.kind == 1) {
+            ctx->nn_gen[op.dir]++;
+            ctx->nn[op.dir].valid = true;
+        } else if (op.kind == 2) {
+            ReduceSlot &s = ctx->slots[op.slot];
+            if (s.pending && s.gen == ctx->nn_gen[s.dir]) PCCM_HIP(hipEventSynchronize(s.ev));   // still in use by someone else
+            s.dir = op.snap.dir; s.metric = op.snap.metric; s.mode = op.snap.mode;
+            s.n_iter = op.snap.n_iter; s.begin = op.snap.begin; s.end = op.snap.end;
+            s.nunits = op.snap.nunits; s.t0 = op.snap.t0; s.tail_n = op.snap.tail_n;
+            s.gen = ctx->nn_gen[s.dir];
+            s.pending = true;
+        }
+    }
+    PCCM_HIP(hipGraphLaunch(g.exec, ctx->stream));
+    for (auto &op : g.ops)
+        if (op.kind == 2) PCCM_HIP(hipEventRecord(ctx->slots[op.slot].ev, ctx->stream));
+    return PCCM_OK;
+}
+
+int pccm_graph_begin(pccm_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    if (ctx->capturing) return fail(PCCM_E_STATE, "already capturing");
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &s : ctx->slots) s.pending = false;      // nothing outside the graph may be half-consumed
+    ctx->cap_ops.clear();
+    ctx->capture_failed = false;
+    PCCM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return PCCM_OK;
+}
+
+int pccm_graph_end(pccm_ctx *ctx, int *graph_id)
+{
+    CHECK_CTX(ctx);
+    if (!graph_id) return fail(PCCM_E_ARG, "null pointer");
+    if (!ctx->capturing) return fail(PCCM_E_STATE, "pccm_graph_begin was not called");
+    ctx->capturing = false;
+    GraphRec g;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g.graph);
+    if (e != hipSuccess || ctx->capture_failed || !g.graph) {
+        (void)hipGetLastError();
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        // whatever the captured calls recorded on the host never ran on the GPU
+        for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
+        for (auto &s : ctx->slots) s.pending = false;
+        grid_invalidate(ctx);
+        return fail(PCCM_E_STATE, "graph capture failed (%s); the context is usable, results were invalidated",
+                    e != hipSuccess ? hipGetErrorString(e) : "a captured call reported an error");
+    }
+    e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g.graph);
+        for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
+        for (auto &s : ctx->slots) s.pending = false;
+        grid_invalidate(ctx);
+        return fail(PCCM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    g.ops = ctx->cap_ops;
+    g.epoch = ctx->epoch;
+    g.valid = true;
+    // the captured calls changed the host bookkeeping but nothing ran yet: run the graph once now
+    PCCM_HIP(hipGraphLaunch(g.exec, ctx->stream));
+    for (auto &op : g.ops)
+        if (op.kind == 2) PCCM_HIP(hipEventRecord(ctx->slots[op.slot].ev, ctx->stream));
+    int id = -1;
+    for (size_t k = 0; k < ctx->graphs.size(); ++k)
+        if (!ctx->graphs[k].valid && !ctx->graphs[k].exec) { id = (int)k; break; }
+    if (id < 0) { ctx->graphs.emplace_back(); id = (int)ctx->graphs.size() - 1; }
+    ctx->graphs[id] = g;
+    *graph_id = id;
+    return PCCM_OK;
+}
+
+int pccm_graph_launch(pccm_ctx *ctx, int graph_id)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (graph_id < 0 || graph_id >= (int)ctx->graphs.size() || !ctx->graphs[graph_id].valid)
+        return fail(PCCM_E_ARG, "unknown graph %d", graph_id);
+    GraphRec &g = ctx->graphs[graph_id];
+    if (g.epoch != ctx->epoch) {
+        graph_free(g);
+        return fail(PCCM_E_STATE, "graph %d is stale: inputs, shard or buffers changed since it was captured", graph_id);
+    }
+    return graph_replay(ctx, g);
+}
+
+int pccm_graph_destroy(pccm_ctx *ctx, int graph_id)
+{
+    CHECK_CTX(ctx);
+    if (graph_id < 0 || graph_id >= (int)ctx->graphs.size()) return fail(PCCM_E_ARG, "unknown graph %d", graph_id);
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    graph_free(ctx->graphs[graph_id]);
     return PCCM_OK;
 }
 
 int pccm_sync(pccm_ctx *ctx)
 {
     CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     return PCCM_OK;
 }
@@ -585,6 +832,7 @@ int pccm_profile_get(pccm_ctx *ctx, int kernel_class, double *ms_total, int64_t 
 int pccm_nn_stats(pccm_ctx *ctx, int dir, int64_t out[3])
 {
     CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
     if (!out) return fail(PCCM_E_ARG, "null pointer");
     const Cloud *it, *se;
     NNResult *res;

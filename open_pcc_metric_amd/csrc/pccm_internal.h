@@ -66,9 +66,34 @@ struct Grid {
     DevBuf recs;                   // GridRec [n]
 };
 
+struct ReduceSlot {            // one enqueued reduction (pccm_reduce_prefetch / pccm_reduce)
+    bool pending = false;
+    int dir = 0, metric = 0, mode = 0;
+    uint64_t gen = 0;          // nn generation of `dir` it was computed from
+    int64_t n_iter = 0, begin = 0, end = 0, nunits = 0, t0 = 0, tail_n = 0;
+    DevBuf val, unit;
+    double *host = nullptr;    // pinned: [3][nunits] unit sums/min/max, then tail_n raw values
+    size_t host_cap = 0;
+    hipEvent_t ev = nullptr;
+};
+
 struct ProfSpan {
     hipEvent_t a, b;
     int cls;
+};
+
+struct GraphOp {               // host-side effect of one captured call, replayed by pccm_graph_launch
+    int kind = 0;              // 0 drop_caches, 1 nn(dir), 2 reduce_prefetch(slot)
+    int dir = 0, slot = -1;
+    ReduceSlot snap;           // kind 2: the slot's bookkeeping at capture time (pointers are not owned)
+};
+
+struct GraphRec {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<GraphOp> ops;
+    uint64_t epoch = 0;        // pccm_ctx::epoch it was captured under
+    bool valid = false;
 };
 
 }  // namespace pccm
@@ -83,8 +108,16 @@ struct pccm_ctx {
     // scratch
     pccm::DevBuf part_b1, part_g, part_b2, flagged, flag_thr, val, unit, stats, staging, counters;
     pccm::Grid grid[2];
-    pccm::DevBuf g_cell_of, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch
+    pccm::DevBuf g_cell_of, g_hist, g_blocksum, g_qrecs, g_tail, g_tailcount;   // grid-engine scratch
     std::vector<double> host_unit;
+    pccm::ReduceSlot slots[8];
+    uint64_t nn_gen[3] = {1, 1, 1};
+    // hipGraph capture of a step (pccm_graph_*): epoch changes whenever inputs, shard or any device
+    // buffer a captured kernel may reference changes, which invalidates every recorded graph
+    uint64_t epoch = 1;
+    bool capturing = false, capture_failed = false;
+    std::vector<pccm::GraphOp> cap_ops;
+    std::vector<pccm::GraphRec> graphs;
     // profiling
     bool prof_on = false;
     std::vector<pccm::ProfSpan> spans;
