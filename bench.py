@@ -170,8 +170,10 @@ def main():
     elif gq_n:
         avg_ms = gq_ms / gq_n
         q_rows = (pair._engine.shard_range(0)[1] - pair._engine.shard_range(0)[0])
-        ncells = n / 2.0
-        alg_bytes = 44.0 * q_rows + 32.0 * n + 4.0 * ncells       # query record + (idx, d2) out, search records, cell bounds
+        ncells = n / 1.5
+        # one launch serves BOTH directions (pccm_nn_pair).  DESIGN.md section 3, per direction:
+        # query record in + (idx, d2) out = 44 B/query, searched records 32 B/point, cell bounds 4 B/cell
+        alg_bytes = 2.0 * (44.0 * q_rows + 32.0 * n + 4.0 * ncells)
         roofline = {"bound": "hbm", "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "traffic": None, "kernel": "grid_query (k_grid_query_coop + tail kernels)",

@@ -110,6 +110,10 @@ int pccm_shard_range(pccm_ctx *ctx, int dir, int64_t *begin, int64_t *end);
  * smallest row index.  Asynchronous on the context's stream; results stay on the device. */
 int pccm_nn(pccm_ctx *ctx, int dir, int engine);
 
+/* PCCM_DIR_LEFT and PCCM_DIR_RIGHT together -- what CloudPair.__init__ does at cloud_pair.py:67-78.
+ * Same results as two pccm_nn() calls; the grid engine fuses both directions into the same launches. */
+int pccm_nn_pair(pccm_ctx *ctx, int engine);
+
 /* Copy the shard's results to the host (either pointer may be NULL).  idx[i] is the row in
  * the searched cloud, d2[i] the squared distance: the (idxs, sqrdists) of cloud_pair.py:32-33
  * and the value behind get_left/right_neighbour_distances(), cloud_pair.py:102-106. */

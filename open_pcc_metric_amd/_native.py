@@ -27,7 +27,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy",
-    "pccm_set_cloud", "pccm_set_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_fetch",
+    "pccm_set_cloud", "pccm_set_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce", "pccm_finish_sum",
     "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
@@ -69,6 +69,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_set_shard.argtypes = [vp, i32, i32]
     lib.pccm_shard_range.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.pccm_nn.argtypes = [vp, i32, i32]
+    lib.pccm_nn_pair.argtypes = [vp, i32]
     lib.pccm_nn_fetch.argtypes = [vp, i32, vp, vp]
     lib.pccm_error_vectors.argtypes = [vp, i32, vp]
     lib.pccm_point_metric.argtypes = [vp, i32, i32, i32, vp]
@@ -197,6 +198,10 @@ class Engine:
     # -- nearest neighbours -----------------------------------------------------------------
     def nn(self, direction: int, engine: str = "auto") -> None:
         _check(self._lib.pccm_nn(self._ctx, int(direction), ENGINES[engine]))
+
+    def nn_pair(self, engine: str = "auto") -> None:
+        """Both directional sweeps of CloudPair.__init__ (cloud_pair.py:67-78) in one call."""
+        _check(self._lib.pccm_nn_pair(self._ctx, ENGINES[engine]))
 
     def fetch_nn(self, direction: int, want_idx: bool = True, want_d2: bool = True):
         b, e = self.shard_range(direction)

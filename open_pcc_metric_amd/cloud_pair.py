@@ -241,8 +241,11 @@ class CloudPair:
         eng = self._engine
         if hasattr(eng, "drop_caches"):
             eng.drop_caches()                                 # search structures are rebuilt, like the KD-trees
-        eng.nn(nat.DIR_LEFT, self.nn_engine)
-        eng.nn(nat.DIR_RIGHT, self.nn_engine)
+        if hasattr(eng, "nn_pair"):
+            eng.nn_pair(self.nn_engine)                       # cloud_pair.py:67-78, both directions fused
+        else:
+            eng.nn(nat.DIR_LEFT, self.nn_engine)
+            eng.nn(nat.DIR_RIGHT, self.nn_engine)
 
     # -- helpers ------------------------------------------------------------------------------
     def _gather(self, direction: int, local: np.ndarray) -> np.ndarray:

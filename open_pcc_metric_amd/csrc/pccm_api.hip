@@ -108,6 +108,10 @@ static void free_cloud(Cloud &c)
 
 static void free_nn(NNResult &r)
 {
+    free_buf(r.flagged);
+    free_buf(r.flag_thr);
+    free_buf(r.tail);
+    free_buf(r.qrecs);
     if (r.idx) (void)hipFree(r.idx);
     if (r.d2) (void)hipFree(r.d2);
     r.idx = nullptr;
@@ -212,13 +216,13 @@ int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
         }
         ctx->own_stream = true;
     }
-    int rc = ensure(ctx, ctx->counters, 3 * sizeof(uint32_t));
+    int rc = ensure(ctx, ctx->counters, 6 * sizeof(uint32_t));
     if (!rc) rc = ensure(ctx, ctx->stats, 9 * sizeof(unsigned long long));
     if (rc) {
         pccm_ctx_destroy(ctx);
         return rc;
     }
-    for (int d = 0; d < 3; ++d) ctx->nn[d].nflag_dev = (uint32_t *)ctx->counters.p + d;
+    for (int d = 0; d < 3; ++d) ctx->nn[d].nflag_dev = (uint32_t *)ctx->counters.p + 2 * d;
     *out = ctx;
     return PCCM_OK;
 }
@@ -235,8 +239,8 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
     for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
-    DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->flagged, &ctx->flag_thr,
-                      &ctx->val, &ctx->unit, &ctx->stats, &ctx->staging, &ctx->counters};
+    DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->unit, &ctx->stats, &ctx->staging,
+                      &ctx->counters};
     for (DevBuf *b : bufs) free_buf(*b);
     for (auto &g : ctx->graphs) graph_free(g);
     for (auto &s : ctx->slots) {
@@ -363,13 +367,12 @@ int pccm_shard_range(pccm_ctx *ctx, int dir, int64_t *begin, int64_t *end)
     return PCCM_OK;
 }
 
-int pccm_nn(pccm_ctx *ctx, int dir, int engine)
+// shard range, result buffers and bookkeeping of one direction; *trivial = 1 when nothing is left to compute
+static int prepare_nn(pccm_ctx *ctx, int dir, int *trivial)
 {
-    CHECK_CTX(ctx);
     const Cloud *it, *se;
     int rc = dir_clouds(ctx, dir, &it, &se);
     if (rc) return rc;
-    const bool self = dir == PCCM_DIR_SELF;
     NNResult &res = ctx->nn[dir];
     res.valid = false;
     ctx->nn_gen[dir]++;
@@ -388,34 +391,72 @@ int pccm_nn(pccm_ctx *ctx, int dir, int engine)
         }
         ctx->epoch++;
         PCCM_HIP(hipStreamSynchronize(ctx->stream));
-        free_nn(res);
+        if (res.idx) (void)hipFree(res.idx);
+        if (res.d2) (void)hipFree(res.d2);
+        res.idx = nullptr;
+        res.d2 = nullptr;
+        res.cap = 0;
         PCCM_HIP(hipMalloc((void **)&res.idx, (size_t)ns * sizeof(int32_t)));
         PCCM_HIP(hipMalloc((void **)&res.d2, (size_t)ns * sizeof(double)));
         res.cap = ns;
     }
     res.stats[0] = res.stats[1] = res.stats[2] = 0;
-    if (self && it->n < 2) {
+    *trivial = 0;
+    if (dir == PCCM_DIR_SELF && it->n < 2) {
         // Open3D's compute_nearest_neighbor_distance returns zeros for fewer than two points
         if (ns > 0) {
             PCCM_HIP(hipMemsetAsync(res.idx, 0xff, (size_t)ns * sizeof(int32_t), ctx->stream));
             PCCM_HIP(hipMemsetAsync(res.d2, 0, (size_t)ns * sizeof(double), ctx->stream));
         }
-        PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, sizeof(uint32_t), ctx->stream));
-        res.valid = true;
-        return PCCM_OK;
+        PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
+        *trivial = 1;
     }
-    if (engine == PCCM_ENGINE_AUTO) {
-        const char *e = getenv("PCCM_ENGINE");
-        if (e && !strcmp(e, "brute")) engine = PCCM_ENGINE_BRUTE;
-        else if (e && !strcmp(e, "grid")) engine = PCCM_ENGINE_GRID;
-        else engine = PCCM_ENGINE_GRID;
-    }
-    if (engine == PCCM_ENGINE_BRUTE) rc = nn_brute(ctx, *it, *se, self, res);
-    else if (engine == PCCM_ENGINE_GRID) rc = nn_grid(ctx, dir, *it, *se, self, res);
-    else return fail(PCCM_E_ARG, "unknown engine %d", engine);
-    if (rc) return rc;
-    res.valid = true;
     return PCCM_OK;
+}
+
+static int pick_engine(int engine)
+{
+    if (engine != PCCM_ENGINE_AUTO) return engine;
+    const char *e = getenv("PCCM_ENGINE");
+    if (e && !strcmp(e, "brute")) return PCCM_ENGINE_BRUTE;
+    return PCCM_ENGINE_GRID;
+}
+
+static int run_nn(pccm_ctx *ctx, int ndirs, const int *dirs, int engine)
+{
+    engine = pick_engine(engine);
+    if (engine != PCCM_ENGINE_BRUTE && engine != PCCM_ENGINE_GRID) return fail(PCCM_E_ARG, "unknown engine %d", engine);
+    int todo[3], ntodo = 0, rc;
+    for (int k = 0; k < ndirs; ++k) {
+        int trivial = 0;
+        if ((rc = prepare_nn(ctx, dirs[k], &trivial))) return rc;
+        if (!trivial) todo[ntodo++] = dirs[k];
+    }
+    if (engine == PCCM_ENGINE_GRID) {
+        if (ntodo > 0 && (rc = nn_grid(ctx, ntodo, todo))) return rc;
+    } else {
+        for (int k = 0; k < ntodo; ++k) {
+            const Cloud *it, *se;
+            if ((rc = dir_clouds(ctx, todo[k], &it, &se))) return rc;
+            if ((rc = nn_brute(ctx, *it, *se, todo[k] == PCCM_DIR_SELF, ctx->nn[todo[k]]))) return rc;
+        }
+    }
+    for (int k = 0; k < ndirs; ++k) ctx->nn[dirs[k]].valid = true;
+    return PCCM_OK;
+}
+
+int pccm_nn(pccm_ctx *ctx, int dir, int engine)
+{
+    CHECK_CTX(ctx);
+    if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
+    return run_nn(ctx, 1, &dir, engine);
+}
+
+int pccm_nn_pair(pccm_ctx *ctx, int engine)
+{
+    CHECK_CTX(ctx);
+    const int dirs[2] = {PCCM_DIR_LEFT, PCCM_DIR_RIGHT};
+    return run_nn(ctx, 2, dirs, engine);
 }
 
 static int need_nn(pccm_ctx *ctx, int dir, const Cloud **it, const Cloud **se, NNResult **res)

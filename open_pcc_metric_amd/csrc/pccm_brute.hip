@@ -343,11 +343,11 @@ int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, 
     dim3 grid((unsigned)(nq < 2048 ? nq : 2048));
     if (self)
         hipLaunchKernelGGL((k2b_fallback<true>), grid, dim3(256), 0, ctx->stream, (const float *)it.xyz32, it.xyz64, res.begin,
-                           (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)ctx->flagged.p, (const float *)ctx->flag_thr.p,
+                           (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)res.flagged.p, (const float *)res.flag_thr.p,
                            res.nflag_dev, res.idx, res.d2);
     else
         hipLaunchKernelGGL((k2b_fallback<false>), grid, dim3(256), 0, ctx->stream, (const float *)it.xyz32, it.xyz64, res.begin,
-                           (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)ctx->flagged.p, (const float *)ctx->flag_thr.p,
+                           (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)res.flagged.p, (const float *)res.flag_thr.p,
                            res.nflag_dev, res.idx, res.d2);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
@@ -373,9 +373,9 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
     if ((rc = ensure(ctx, ctx->part_b1, (size_t)splits * nq * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->part_g, (size_t)splits * nq * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->part_b2, (size_t)splits * nq * sizeof(float)))) return rc;
-    if ((rc = ensure(ctx, ctx->flagged, (size_t)nq * sizeof(int32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->flag_thr, (size_t)nq * sizeof(float)))) return rc;
-    PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, sizeof(uint32_t), ctx->stream));
+    if ((rc = ensure(ctx, res.flagged, (size_t)nq * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, res.flag_thr, (size_t)nq * sizeof(float)))) return rc;
+    PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
 
     float *pb1 = (float *)ctx->part_b1.p;
     int32_t *pg = (int32_t *)ctx->part_g.p;
@@ -399,12 +399,12 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
         dim3 grid((unsigned)((waves + 3) / 4));
         if (self)
             hipLaunchKernelGGL((k2_refine<true>), grid, dim3(256), 0, ctx->stream, it.xyz64, res.begin, nq, se.xyz64, se.n,
-                               pb1, pg, pb2, (int)splits, slack, res.idx, res.d2, (int32_t *)ctx->flagged.p,
-                               (float *)ctx->flag_thr.p, res.nflag_dev);
+                               pb1, pg, pb2, (int)splits, slack, res.idx, res.d2, (int32_t *)res.flagged.p,
+                               (float *)res.flag_thr.p, res.nflag_dev);
         else
             hipLaunchKernelGGL((k2_refine<false>), grid, dim3(256), 0, ctx->stream, it.xyz64, res.begin, nq, se.xyz64, se.n,
-                               pb1, pg, pb2, (int)splits, slack, res.idx, res.d2, (int32_t *)ctx->flagged.p,
-                               (float *)ctx->flag_thr.p, res.nflag_dev);
+                               pb1, pg, pb2, (int)splits, slack, res.idx, res.d2, (int32_t *)res.flagged.p,
+                               (float *)res.flag_thr.p, res.nflag_dev);
     }
     PCCM_HIP(hipGetLastError());
     if ((rc = launch_fallback(ctx, it, se, self, res))) return rc;

@@ -1,28 +1,32 @@
 // Uniform-grid exact 1-NN engine for gfx950.
 //
 // Replaces the same reference interface as the brute-force engine -- get_neighbour_cloud(),
-// open_pcc_metric/cloud_pair.py:10-42, and the KD-tree builds of cloud_pair.py:65 -- with
-// O(N) work: the searched cloud is counting-sorted into a uniform grid (the analogue of the
-// reference's KDTreeFlann build), every query scans the 3x3x3 cells around its own cell and
-// widens ring by ring until the best distance found is provably smaller than the distance to
-// anything not scanned yet.  All candidate distances are evaluated in fp64 with the reference's
-// arithmetic ((dx*dx)+(dy*dy))+(dz*dz) (no FMA), exact ties go to the smallest original row:
-// results are bit-identical to the brute-force engine and to the oracle.
+// open_pcc_metric/cloud_pair.py:10-42, and the KD-tree builds of cloud_pair.py:65 -- with O(N) work:
+// both clouds are counting-sorted into ONE uniform grid geometry (the analogue of the reference's two
+// KDTreeFlann builds), every query scans the 3x3x3 cells around its own cell and widens ring by ring
+// until the best distance found is provably smaller than the distance to anything not scanned yet.
+// Winners are decided in fp64 with the reference's arithmetic ((dx*dx)+(dy*dy))+(dz*dz) (no FMA), exact
+// ties go to the smallest original row: results are bit-identical to the brute-force engine and to the
+// oracle.
 //
-// Data layout in HBM: GridRec = {double x, y, z; int32 row; pad} (32 B, two 16-byte loads) sorted
-// by cell, cells in x-fastest order, so the 3 cells of one x-run are one contiguous range and a
-// 3x3x3 neighbourhood is 9 ranges; cell_start is uint32[ncells + 1].  Queries are processed in
-// cell-sorted order too (the iterating cloud's own grid records, or the shard's rows sorted by
-// the searched grid's cells), so the lanes of a wave walk the same ranges and their loads
-// coalesce in L1/L2.  The kernel is latency/L2-bound: ~54 candidates x 32 B per query, ALU work
-// is negligible (DESIGN.md gives the byte model).
+// Data layout in HBM: GridRec = {double x, y, z; int32 row; pad} (32 B) for BOTH clouds in one array
+// (cloud A's records, then cloud B's), sorted by cell within each cloud, cells in x-fastest order, so
+// the 3 cells of one x-run are one contiguous range and a 3x3x3 neighbourhood is 9 ranges;
+// cell_start is uint32[2][ncells + 1] holding positions in the combined array.  Queries are processed
+// in cell-sorted order (the iterating cloud's own records, or a shard's rows sorted by the same cells).
+//
+// Launch structure (everything that exists per direction or per cloud is fused into one launch over
+// "jobs", because at these sizes the kernels are latency-bound and launches cost ~5 us each):
+//   build   k_grid_cells (cell id + rank by atomicAdd, both clouds) -> exclusive scan -> k_grid_scatter
+//   query   k_grid_query_coop (ring 1, fp32 in LDS, fp64 certification; both directions)
+//           -> k_grid_tail_wave (few unsettled queries: one wave each, rings 1..kMaxRing)
+//           -> k_grid_query (many unsettled queries, e.g. lattice data: one thread each)
+//           -> k2b_fallback of the brute engine (still unsettled after kMaxRing rings)
 //
 // Exactness of the stop rule.  cell(x) = clamp(floor((x - org) * inv_h)) is monotonic in x, so a
 // point in a cell left of cell c lies below org + c*h up to a few ulps of the grid's size; the
-// kernel subtracts that slack (g.slack[a]) from every face distance and compares with a strict
+// kernels subtract that slack (g.slack[a]) from every face distance and compare with a strict
 // "<" after shrinking the bound by 2^-30, so a stop is never taken on a rounding coincidence.
-// Queries that are still unresolved after kMaxRing rings are handed to the brute engine's exact
-// rescan kernel (k2b_fallback) with the best distance found so far as the candidate threshold.
 #include "pccm_internal.h"
 
 namespace pccm {
@@ -55,38 +59,55 @@ __device__ __forceinline__ double gdist64(double qx, double qy, double qz, doubl
     return d;
 }
 
-// ---- build: cell ids + histogram, scan, scatter ------------------------------------------------
-__global__ __launch_bounds__(256) void k_grid_cells(const double *__restrict__ x64, int64_t row0, int64_t n,
-                                                    GridGeom g, uint32_t *__restrict__ cell_of,
-                                                    uint32_t *__restrict__ hist)
+__device__ __forceinline__ int rec_row(const double4 &a) { return (int)(__double_as_longlong(a.w) & 0xffffffffll); }
+
+// ---- build: cell id + rank (one atomic per point), scan, scatter (no atomics) ------------------------
+struct BuildJob {
+    const double *x64;   // [.][3]
+    int64_t row0, n;     // rows [row0, row0 + n)
+    uint32_t *cs;        // this job's cell counters / starts, [ncells + 1]
+};
+
+struct BuildJobs {
+    BuildJob j[2];
+    int njobs;
+    int64_t total;
+};
+
+__global__ __launch_bounds__(256) void k_grid_cells(BuildJobs jobs, GridGeom g, uint32_t *__restrict__ cell_of,
+                                                    uint32_t *__restrict__ rank)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double *p = x64 + 3 * (row0 + i);
+    if (i >= jobs.total) return;
+    const int which = (jobs.njobs > 1 && i >= jobs.j[0].n) ? 1 : 0;
+    const BuildJob &J = jobs.j[which];
+    const int64_t li = which ? i - jobs.j[0].n : i;
+    const double *p = J.x64 + 3 * (J.row0 + li);
     const int cx = cell_coord(p[0], g.org[0], g.inv_h[0], g.dim[0]);
     const int cy = cell_coord(p[1], g.org[1], g.inv_h[1], g.dim[1]);
     const int cz = cell_coord(p[2], g.org[2], g.inv_h[2], g.dim[2]);
     const uint32_t c = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
     cell_of[i] = c;
-    atomicAdd(&hist[c], 1u);
+    rank[i] = atomicAdd(&J.cs[c], 1u);
 }
 
-__global__ __launch_bounds__(256) void k_grid_scatter(const double *__restrict__ x64, int64_t row0, int64_t n,
-                                                      const uint32_t *__restrict__ cell_of,
-                                                      uint32_t *__restrict__ cursor, GridRec *__restrict__ recs)
+__global__ __launch_bounds__(256) void k_grid_scatter(BuildJobs jobs, const uint32_t *__restrict__ cell_of,
+                                                      const uint32_t *__restrict__ rank, GridRec *__restrict__ recs)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double *p = x64 + 3 * (row0 + i);
-    const uint32_t pos = atomicAdd(&cursor[cell_of[i]], 1u);
-    GridRec r;
+    if (i >= jobs.total) return;
+    const int which = (jobs.njobs > 1 && i >= jobs.j[0].n) ? 1 : 0;
+    const BuildJob &J = jobs.j[which];
+    const int64_t li = which ? i - jobs.j[0].n : i;
+    const double *p = J.x64 + 3 * (J.row0 + li);
+    const uint32_t pos = J.cs[cell_of[i]] + rank[i];
+    double4 r;
     r.x = p[0]; r.y = p[1]; r.z = p[2];
-    r.idx = (int32_t)(row0 + i);
-    r.pad = 0;
-    recs[pos] = r;
+    r.w = __longlong_as_double((long long)(uint32_t)(J.row0 + li));
+    *reinterpret_cast<double4 *>(&recs[pos]) = r;
 }
 
-// exclusive prefix sum of uint32 data[0..m) in place: block scan, scan of block totals, add back
+// exclusive prefix sum of uint32 data[0..m) in place: block scan, offsets of the block totals, add back
 __global__ __launch_bounds__(256) void k_scan_block(uint32_t *__restrict__ data, int64_t m, uint32_t *__restrict__ blocksum)
 {
     __shared__ uint32_t wsum[4];
@@ -144,9 +165,24 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ block
     }
 }
 
+// add-back.  SUMMED: blocksum already holds exclusive offsets (k_scan_sums ran); otherwise every
+// block first adds up the totals of the blocks before it (few blocks: saves the k_scan_sums launch).
+template <bool SUMMED>
 __global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ data, int64_t m, const uint32_t *__restrict__ blocksum)
 {
-    const uint32_t add = blocksum[blockIdx.x];
+    __shared__ uint32_t part[4];
+    uint32_t add;
+    if (SUMMED) {
+        add = blocksum[blockIdx.x];
+    } else {
+        uint32_t s = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) s += blocksum[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        add = part[0] + part[1] + part[2] + part[3];
+    }
     const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanItems;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
@@ -160,37 +196,55 @@ static int exclusive_scan(pccm_ctx *ctx, uint32_t *data, int64_t m)
     if (rc) return rc;
     uint32_t *bs = (uint32_t *)ctx->g_blocksum.p;
     hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, ctx->stream, data, m, bs);
-    if (nb > 1) {
+    if (nb > 1 && nb <= 2048) {
+        hipLaunchKernelGGL((k_scan_add<false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, data, m, (const uint32_t *)bs);
+    } else if (nb > 1) {
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, bs, nb);
-        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(256), 0, ctx->stream, data, m, bs);
+        hipLaunchKernelGGL((k_scan_add<true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, data, m, (const uint32_t *)bs);
     }
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
 
-// counting sort of rows [row0, row0+n) of x64 by cell of geometry g:
-// cell_start (uint32[ncells+1], may be null for a throw-away histogram) and recs[n]
-static int sort_by_cell(pccm_ctx *ctx, const double *x64, int64_t row0, int64_t n, const GridGeom &g, int64_t ncells,
-                        uint32_t *cell_start, GridRec *recs)
+// counting sort by cell: cs_all = the jobs' counters, contiguous, [cs_len]; on return they hold the
+// exclusive starts (positions in recs, running across the jobs) and recs is filled
+static int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, uint32_t *cs_all, int64_t cs_len,
+                        GridRec *recs)
 {
     int rc;
-    if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)n * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->g_hist, (size_t)(ncells + 1) * sizeof(uint32_t)))) return rc;
-    uint32_t *cell_of = (uint32_t *)ctx->g_cell_of.p;
-    uint32_t *cursor = (uint32_t *)ctx->g_hist.p;
-    uint32_t *hist = cell_start ? cell_start : cursor;
-    PCCM_HIP(hipMemsetAsync(hist, 0, (size_t)(ncells + 1) * sizeof(uint32_t), ctx->stream));
-    dim3 grid((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL(k_grid_cells, grid, dim3(256), 0, ctx->stream, x64, row0, n, g, cell_of, hist);
-    if ((rc = exclusive_scan(ctx, hist, ncells + 1))) return rc;
-    if (cell_start)
-        PCCM_HIP(hipMemcpyAsync(cursor, cell_start, (size_t)(ncells + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_grid_scatter, grid, dim3(256), 0, ctx->stream, x64, row0, n, cell_of, cursor, recs);
+    if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)jobs.total * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->g_rank, (size_t)jobs.total * sizeof(uint32_t)))) return rc;
+    uint32_t *cell_of = (uint32_t *)ctx->g_cell_of.p, *rank = (uint32_t *)ctx->g_rank.p;
+    PCCM_HIP(hipMemsetAsync(cs_all, 0, (size_t)cs_len * sizeof(uint32_t), ctx->stream));
+    dim3 grid((unsigned)((jobs.total + 255) / 256));
+    hipLaunchKernelGGL(k_grid_cells, grid, dim3(256), 0, ctx->stream, jobs, g, cell_of, rank);
+    if ((rc = exclusive_scan(ctx, cs_all, cs_len))) return rc;
+    hipLaunchKernelGGL(k_grid_scatter, grid, dim3(256), 0, ctx->stream, jobs, (const uint32_t *)cell_of, (const uint32_t *)rank, recs);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
 
-// ---- query --------------------------------------------------------------------------------------
+// ---- query --------------------------------------------------------------------------------------------
+struct QueryJob {
+    const GridRec *qrecs;       // cell-sorted queries
+    int64_t nq, nchunks;        // nchunks = ceil(nq / 64)
+    const uint32_t *cs;         // searched cloud's cell starts (positions in srecs)
+    const GridRec *srecs;       // combined record array
+    int64_t row_base;           // first row of the shard (outputs are indexed row - row_base)
+    double slack32;             // fp32 rounding slack of inexact inputs (see pccm_brute.hip)
+    int32_t *idx_out;
+    double *d2_out;
+    GridRec *tail;              // queries ring 1 could not settle
+    int32_t *flagged;           // queries for the brute engine's exact rescan
+    float *flag_thr;
+    uint32_t *counters;         // [0] = number flagged, [1] = tail length
+};
+
+struct QueryJobs {
+    QueryJob j[2];
+    int njobs;
+};
+
 struct Best {
     double d;
     int idx;
@@ -198,7 +252,7 @@ struct Best {
 
 __device__ __forceinline__ void consider(const double4 &a, double qx, double qy, double qz, int qrow, bool self, Best &b)
 {
-    const int row = (int)(__double_as_longlong(a.w) & 0xffffffffll);
+    const int row = rec_row(a);
     const double d = gdist64(qx, qy, qz, a.x, a.y, a.z);
     bool better = d < b.d || (d == b.d && row < b.idx);
     if (self) better = better && (row != qrow);
@@ -227,97 +281,111 @@ __device__ __forceinline__ void scan_range(const GridRec *__restrict__ recs, uin
     }
 }
 
-template <bool SELF>
-__global__ __launch_bounds__(256) void k_grid_query(const GridRec *__restrict__ qrecs, int64_t nq_host,
-                                                    const uint32_t *__restrict__ nq_dev, GridGeom g,
-                                                    const uint32_t *__restrict__ cell_start,
-                                                    const GridRec *__restrict__ srecs, int64_t row_base, double slack32,
-                                                    int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
-                                                    int32_t *__restrict__ flagged, float *__restrict__ flag_thr,
-                                                    uint32_t *__restrict__ nflag)
+// distance from q to the nearest face of the cube [c-r, c+r]^3 that still has cells behind it
+__device__ __forceinline__ double face_bound(const GridGeom &g, double qx, double qy, double qz, int cx, int cy, int cz, int r)
 {
-    // the query count is a host value (direct launch) or lives on the device (tail of the cooperative kernel)
-    int64_t nq = nq_host;
-    if (nq_dev) {
-        nq = (int64_t)*nq_dev;
-        if (nq <= (int64_t)kTailWaveMax) return;        // short tail: k_grid_tail_wave handled it
+    double L = INFINITY;
+    const double q[3] = {qx, qy, qz};
+    const int c[3] = {cx, cy, cz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (c[a] - r > 0) L = fmin(L, (q[a] - (g.org[a] + (double)(c[a] - r) * g.h[a])) - g.slack[a]);
+        if (c[a] + r < g.dim[a] - 1) L = fmin(L, ((g.org[a] + (double)(c[a] + r + 1) * g.h[a]) - q[a]) - g.slack[a]);
     }
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nq; t += (int64_t)gridDim.x * 256) {
-    const double4 qa = *reinterpret_cast<const double4 *>(&qrecs[t]);
-    const double qx = qa.x, qy = qa.y, qz = qa.z;
-    const int qrow = (int)(__double_as_longlong(qa.w) & 0xffffffffll);
-    const int cx = cell_coord(qx, g.org[0], g.inv_h[0], g.dim[0]);
-    const int cy = cell_coord(qy, g.org[1], g.inv_h[1], g.dim[1]);
-    const int cz = cell_coord(qz, g.org[2], g.inv_h[2], g.dim[2]);
-    const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
+    return L;
+}
 
-    Best b;
-    b.d = INFINITY;
-    b.idx = 0x7fffffff;
-    bool done = false;
-    {
-        // ring 1 = the 3x3x3 block: nine x-runs whose bounds are fetched together up front
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, dimx - 1);
-        uint32_t rs[9], re[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int z = cz + k / 3 - 1, y = cy + k % 3 - 1;
-            const bool in = z >= 0 && z < dimz && y >= 0 && y < dimy;
-            const uint32_t row = in ? ((uint32_t)z * dimy + y) * dimx : 0u;
-            const uint32_t a = cell_start[row + x0], c = cell_start[row + x1 + 1];
-            rs[k] = in ? a : 0u;
-            re[k] = in ? c : 0u;
+__device__ __forceinline__ bool settled_by(double L, double d)
+{
+    return (L == INFINITY) || (L > 0.0 && d < L * L * (1.0 - 0x1.0p-30));
+}
+
+__device__ __forceinline__ void flag_for_rescan(const QueryJob &J, int qrow, double best)
+{
+    // every possible winner has d32 <= thr(best so far) -- same bound as k2_refine
+    double tq = (best == INFINITY) ? 1.0e18 : sqrt(best) * (1.0 + 0x1.0p-20) + J.slack32;
+    double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
+    float tf = thr > 3.0e38 ? 3.0e38f : (float)thr;
+    tf = __uint_as_float(__float_as_uint(tf) + 1u);
+    const uint32_t pos = atomicAdd(&J.counters[0], 1u);
+    J.flagged[pos] = (int32_t)(qrow - J.row_base);
+    J.flag_thr[pos] = tf;
+}
+
+// ---- per-thread ring search: the long-tail kernel (and the whole query when PCCM_GRID_COOP=0) --------------
+// One query per thread, rings 1..kMaxRing.  from_tail: the queries are the job's tail list and the kernel
+// only runs when that list is too long for k_grid_tail_wave.
+template <bool SELF>
+__global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g, int from_tail)
+{
+    const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
+    for (int jb = 0; jb < jobs.njobs; ++jb) {
+        const QueryJob &J = jobs.j[jb];
+        const GridRec *__restrict__ qrecs = from_tail ? J.tail : J.qrecs;
+        int64_t nq = J.nq;
+        if (from_tail) {
+            nq = (int64_t)J.counters[1];
+            if (nq <= (int64_t)kTailWaveMax) continue;      // short tail: k_grid_tail_wave handled it
         }
+        const uint32_t *__restrict__ cell_start = J.cs;
+        const GridRec *__restrict__ srecs = J.srecs;
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nq; t += (int64_t)gridDim.x * 256) {
+            const double4 qa = *reinterpret_cast<const double4 *>(&qrecs[t]);
+            const double qx = qa.x, qy = qa.y, qz = qa.z;
+            const int qrow = rec_row(qa);
+            const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
+            const int cy = cell_coord(qy, g.org[1], g.inv_h[1], dimy);
+            const int cz = cell_coord(qz, g.org[2], g.inv_h[2], dimz);
+            Best b;
+            b.d = INFINITY;
+            b.idx = 0x7fffffff;
+            bool done = false;
+            {
+                // ring 1 = the 3x3x3 block: nine x-runs whose bounds are fetched together up front
+                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, dimx - 1);
+                uint32_t rs[9], re[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) scan_range<SELF>(srecs, rs[k], re[k], qx, qy, qz, qrow, b);
-    }
-    for (int r = 1; r <= kMaxRing && !done; ++r) {
-        if (r > 1) {
-        const int z0 = max(cz - r, 0), z1 = min(cz + r, dimz - 1);
-        const int y0 = max(cy - r, 0), y1 = min(cy + r, dimy - 1);
-        const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
-        for (int z = z0; z <= z1; ++z) {
-            const bool zface = (z == cz - r) || (z == cz + r);
-            for (int y = y0; y <= y1; ++y) {
-                const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
-                if (zface || y == cy - r || y == cy + r) {
-                    scan_range<SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
-                } else {                                    // interior of the shell: only the two end cells
-                    if (cx - r >= 0)
-                        scan_range<SELF>(srecs, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, qrow, b);
-                    if (cx + r <= dimx - 1)
-                        scan_range<SELF>(srecs, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, qrow, b);
+                for (int k = 0; k < 9; ++k) {
+                    const int z = cz + k / 3 - 1, y = cy + k % 3 - 1;
+                    const bool in = z >= 0 && z < dimz && y >= 0 && y < dimy;
+                    const uint32_t row = in ? ((uint32_t)z * dimy + y) * dimx : 0u;
+                    const uint32_t a = cell_start[row + x0], c = cell_start[row + x1 + 1];
+                    rs[k] = in ? a : 0u;
+                    re[k] = in ? c : 0u;
                 }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) scan_range<SELF>(srecs, rs[k], re[k], qx, qy, qz, qrow, b);
+            }
+            for (int r = 1; r <= kMaxRing && !done; ++r) {
+                if (r > 1) {
+                    const int z0 = max(cz - r, 0), z1 = min(cz + r, dimz - 1);
+                    const int y0 = max(cy - r, 0), y1 = min(cy + r, dimy - 1);
+                    const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
+                    for (int z = z0; z <= z1; ++z) {
+                        const bool zface = (z == cz - r) || (z == cz + r);
+                        for (int y = y0; y <= y1; ++y) {
+                            const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
+                            if (zface || y == cy - r || y == cy + r) {
+                                scan_range<SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
+                            } else {                                    // interior of the shell: only the two end cells
+                                if (cx - r >= 0)
+                                    scan_range<SELF>(srecs, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, qrow, b);
+                                if (cx + r <= dimx - 1)
+                                    scan_range<SELF>(srecs, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, qrow, b);
+                            }
+                        }
+                    }
+                }
+                done = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, r), b.d);
+            }
+            if (done) {
+                if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }   // SELF on a one-point cloud (host handles it earlier)
+                J.idx_out[qrow - J.row_base] = b.idx;
+                J.d2_out[qrow - J.row_base] = b.d;
+            } else {
+                flag_for_rescan(J, qrow, b.d);
             }
         }
-        }
-        // distance from the query to the nearest face of the scanned cube that still has cells behind it
-        double L = INFINITY;
-        const double q[3] = {qx, qy, qz};
-        const int c[3] = {cx, cy, cz};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (c[a] - r > 0) L = fmin(L, (q[a] - (g.org[a] + (double)(c[a] - r) * g.h[a])) - g.slack[a]);
-            if (c[a] + r < g.dim[a] - 1) L = fmin(L, ((g.org[a] + (double)(c[a] + r + 1) * g.h[a]) - q[a]) - g.slack[a]);
-        }
-        if (L == INFINITY) done = true;                    // the cube covers the whole grid
-        else if (L > 0.0 && b.d < L * L * (1.0 - 0x1.0p-30)) done = true;
-    }
-    if (done) {
-        if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }   // SELF on a one-point cloud (not reached: host handles it)
-        idx_out[qrow - row_base] = b.idx;
-        d2_out[qrow - row_base] = b.d;
-    } else {
-        // unresolved: exact rescan by the brute engine's fallback kernel; every possible winner has
-        // d32 <= thr(best so far) -- same bound as k2_refine
-        double tq = (b.d == INFINITY) ? 1.0e18 : sqrt(b.d) * (1.0 + 0x1.0p-20) + slack32;
-        double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
-        float tf = thr > 3.0e38 ? 3.0e38f : (float)thr;
-        tf = __uint_as_float(__float_as_uint(tf) + 1u);
-        const uint32_t pos = atomicAdd(nflag, 1u);
-        flagged[pos] = (int32_t)(qrow - row_base);
-        flag_thr[pos] = tf;
-    }
     }
 }
 
@@ -328,36 +396,38 @@ __global__ __launch_bounds__(256) void k_grid_query(const GridRec *__restrict__ 
 //   1. fetches all cell bounds with nine coalesced loads issued together (lane i reads
 //      cell_start[x_lo + i]) and hands every lane its own [s, e) per run by shuffle,
 //   2. stages the runs' records into LDS as fp32 SoA (x | y | z [| row]) with coalesced 32-byte-per-lane
-//      loads -- every record is fetched once per wave instead of once per lane,
+//      loads -- every record is fetched once per wave instead of once per lane (the per-thread kernel is
+//      bound by the L1/TA address path: each of its loads touches ~30 cache lines per wave),
 //   3. lets every lane scan only its own candidates from LDS in fp32 (same-cell lanes broadcast),
 //      tracking best d32, its record position and the second-best d32 -- no fp64, no branches,
 //   4. certifies like k2_refine: if the second-best d32 is above thr(best d32) the fp32 winner is the
 //      unique fp64 winner, whose exact d2 is then computed once from its fp64 record.
 // Queries that cannot be certified (near ties, exact ties on lattices) or whose ring-1 result does not
-// satisfy the stop rule go to `tail` and are finished exactly by k_grid_query.
-constexpr int kCap = 768;         // fp32 records staged per wave (9 KB); more -> several windows
+// satisfy the stop rule go to `tail`.
+constexpr int kCap = 384;         // fp32 records staged per wave (4.5 KB); more -> several windows
 constexpr int kSegWidth = 61;     // + 3 bounds = 64 lanes
 constexpr float kBigF = 3.0e38f;
 
 template <bool SELF>
-__global__ __launch_bounds__(256) void k_grid_query_coop(const GridRec *__restrict__ qrecs, int64_t nq, GridGeom g,
-                                                         const uint32_t *__restrict__ cell_start,
-                                                         const GridRec *__restrict__ srecs, int64_t row_base,
-                                                         double slack32, int32_t *__restrict__ idx_out,
-                                                         double *__restrict__ d2_out, GridRec *__restrict__ tail,
-                                                         uint32_t *__restrict__ tailcount)
+__global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeom g)
 {
     __shared__ float lx[4][kCap], ly[4][kCap], lz[4][kCap];
     __shared__ int lrow[SELF ? 4 : 1][SELF ? kCap : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t chunk = (int64_t)blockIdx.x * 4 + w;
+    int64_t chunk = (int64_t)blockIdx.x * 4 + w;
+    const int jb = (jobs.njobs > 1 && chunk >= jobs.j[0].nchunks) ? 1 : 0;     // wave-uniform
+    if (jb) chunk -= jobs.j[0].nchunks;
+    const QueryJob &J = jobs.j[jb];
+    const int64_t nq = J.nq;
     if (chunk * 64 >= nq) return;                       // wave-uniform
+    const uint32_t *__restrict__ cell_start = J.cs;
+    const GridRec *__restrict__ srecs = J.srecs;
     const int64_t t = chunk * 64 + lane;
     const bool valid = t < nq;
-    const double4 qa = *reinterpret_cast<const double4 *>(&qrecs[valid ? t : nq - 1]);
+    const double4 qa = *reinterpret_cast<const double4 *>(&J.qrecs[valid ? t : nq - 1]);
     const double qx = qa.x, qy = qa.y, qz = qa.z;
     const float fx = (float)qx, fy = (float)qy, fz = (float)qz;
-    const int qrow = (int)(__double_as_longlong(qa.w) & 0xffffffffll);
+    const int qrow = rec_row(qa);
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
     const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
     const int cy = cell_coord(qy, g.org[1], g.inv_h[1], dimy);
@@ -378,22 +448,22 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(const GridRec *__restri
         const int x_hi = min(xb + 2, dimx);             // index of the last bound needed
         const int my_s = (max(cx - 1, 0) - x_lo) & 63, my_e = (min(cx + 2, dimx) - x_lo) & 63;
 
-        uint32_t csv[9];
+        // per run k: wave-uniform S (first record), off (start in the flattened candidate list) in
+        // SGPRs; per lane only the flat start and the length of its own three-cell range
+        uint32_t S[9], off[10], rs[9], rl[9];
+        off[0] = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int z = czl + k / 3 - 1, y = cyl + k % 3 - 1;
             const bool in = z >= 0 && z < dimz && y >= 0 && y < dimy;          // wave-uniform
             const uint32_t rowbase = in ? ((uint32_t)z * dimy + y) * dimx : 0u;
-            csv[k] = in ? cell_start[rowbase + min(x_lo + lane, x_hi)] : 0u;
-        }
-        uint32_t s[9], e[9], S[9], off[10];
-        off[0] = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            s[k] = __shfl(csv[k], my_s);
-            e[k] = __shfl(csv[k], my_e);
-            S[k] = __shfl(csv[k], 0);
-            off[k + 1] = off[k] + (__shfl(csv[k], x_hi - x_lo) - S[k]);       // 0 for rows outside the grid
+            const uint32_t csv = in ? cell_start[rowbase + min(x_lo + lane, x_hi)] : 0u;
+            const uint32_t s = __shfl(csv, my_s), e = __shfl(csv, my_e);
+            S[k] = __builtin_amdgcn_readfirstlane(csv);                          // lane 0 holds the bound of x_lo
+            const uint32_t E = __builtin_amdgcn_readfirstlane(__shfl(csv, x_hi - x_lo));
+            off[k + 1] = off[k] + (E - S[k]);                                  // 0 for rows outside the grid
+            rs[k] = off[k] + (s - S[k]);
+            rl[k] = e - s;
         }
         const uint32_t T = off[9];
 
@@ -410,7 +480,7 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(const GridRec *__restri
                     lx[w][f - W0] = (float)r.x;
                     ly[w][f - W0] = (float)r.y;
                     lz[w][f - W0] = (float)r.z;
-                    if (SELF) lrow[w][f - W0] = (int)(__double_as_longlong(r.w) & 0xffffffffll);
+                    if (SELF) lrow[w][f - W0] = rec_row(r);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -419,9 +489,9 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(const GridRec *__restri
             if (inseg) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    const uint32_t fa = off[k] + (s[k] - S[k]), fb = off[k] + (e[k] - S[k]);
+                    const uint32_t fa = rs[k], fb = rs[k] + rl[k];
                     const uint32_t lo = fa > W0 ? fa : W0, hi = fb < W1 ? fb : W1;
-                    const uint32_t delta = S[k] - off[k];
+                    const uint32_t delta = S[k] - off[k];                         // flat position -> record in srecs
                     for (uint32_t f = lo; f < hi; ++f) {
                         const uint32_t o = f - W0;
                         const float dx = fx - lx[w][o], dy = fy - ly[w][o], dz = fz - lz[w][o];
@@ -441,8 +511,8 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(const GridRec *__restri
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (inseg) {
-            // certification (bound derived in pccm_brute.hip) + the ring-1 stop rule of k_grid_query
-            const double tq = sqrt((double)best) * (1.0 + 0x1.0p-20) + slack32;
+            // certification (bound derived in pccm_brute.hip) + the ring-1 stop rule
+            const double tq = sqrt((double)best) * (1.0 + 0x1.0p-20) + J.slack32;
             const double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
             bool settled = false;
             double d64 = 0.0;
@@ -450,23 +520,15 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(const GridRec *__restri
             if (bestpos != 0xffffffffu && (double)second > thr) {
                 const double4 r = *reinterpret_cast<const double4 *>(&srecs[bestpos]);
                 d64 = gdist64(qx, qy, qz, r.x, r.y, r.z);
-                wrow = (int)(__double_as_longlong(r.w) & 0xffffffffll);
-                double L = INFINITY;
-                const double q[3] = {qx, qy, qz};
-                const int c[3] = {cx, cy, cz};
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    if (c[a] - 1 > 0) L = fmin(L, (q[a] - (g.org[a] + (double)(c[a] - 1) * g.h[a])) - g.slack[a]);
-                    if (c[a] + 1 < g.dim[a] - 1) L = fmin(L, ((g.org[a] + (double)(c[a] + 2) * g.h[a]) - q[a]) - g.slack[a]);
-                }
-                settled = (L == INFINITY) || (L > 0.0 && d64 < L * L * (1.0 - 0x1.0p-30));
+                wrow = rec_row(r);
+                settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
             }
             if (settled) {
-                idx_out[qrow - row_base] = wrow;
-                d2_out[qrow - row_base] = d64;
+                J.idx_out[qrow - J.row_base] = wrow;
+                J.d2_out[qrow - J.row_base] = d64;
             } else {
-                const uint32_t pos = atomicAdd(tailcount, 1u);
-                *reinterpret_cast<double4 *>(&tail[pos]) = qa;
+                const uint32_t pos = atomicAdd(&J.counters[1], 1u);
+                *reinterpret_cast<double4 *>(&J.tail[pos]) = qa;
             }
         }
         pending &= ~seg;
@@ -479,75 +541,59 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(const GridRec *__restri
 // and its lanes take one x-run of the cube [c-r, c+r]^3 each ((2r+1)^2 <= 49 runs), so a ring costs one
 // bounds load plus a few batched record loads; the lexicographic (d2, row) minimum is reduced across the
 // wave and the stop rule is evaluated wave-uniformly.  Rings already scanned are simply scanned again
-// (the minimum is idempotent).  Used when the tail is short; long tails (lattice data, where exact ties
-// defeat the fp32 certification) go through the per-thread kernel, which has the parallelism then.
+// (the minimum is idempotent).  Long tails (lattice data, where exact ties defeat the fp32
+// certification) go through k_grid_query instead, which has the parallelism then.
 template <bool SELF>
-__global__ __launch_bounds__(256) void k_grid_tail_wave(const GridRec *__restrict__ tail, const uint32_t *__restrict__ tailcount,
-                                                        GridGeom g, const uint32_t *__restrict__ cell_start,
-                                                        const GridRec *__restrict__ srecs, int64_t row_base, double slack32,
-                                                        int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
-                                                        int32_t *__restrict__ flagged, float *__restrict__ flag_thr,
-                                                        uint32_t *__restrict__ nflag)
+__global__ __launch_bounds__(256) void k_grid_tail_wave(QueryJobs jobs, GridGeom g)
 {
-    const uint32_t count = *tailcount;
-    if (count > kTailWaveMax) return;                   // long tail: k_grid_query handles it
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
-    for (uint32_t qi = wave0; qi < count; qi += nwaves) {
-        const double4 qa = *reinterpret_cast<const double4 *>(&tail[qi]);   // wave-uniform
-        const double qx = qa.x, qy = qa.y, qz = qa.z;
-        const int qrow = (int)(__double_as_longlong(qa.w) & 0xffffffffll);
-        const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
-        const int cy = cell_coord(qy, g.org[1], g.inv_h[1], dimy);
-        const int cz = cell_coord(qz, g.org[2], g.inv_h[2], dimz);
-        Best b;
-        b.d = INFINITY;
-        b.idx = 0x7fffffff;
-        bool done = false;
-        for (int r = 1; r <= kMaxRing && !done; ++r) {
-            const int side = 2 * r + 1;
-            if (lane < side * side) {
-                const int z = cz + lane / side - r, y = cy + lane % side - r;
-                if (z >= 0 && z < dimz && y >= 0 && y < dimy) {
-                    const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
-                    const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
-                    scan_range<SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
+    for (int jb = 0; jb < jobs.njobs; ++jb) {
+        const QueryJob &J = jobs.j[jb];
+        const uint32_t count = J.counters[1];
+        if (count > kTailWaveMax) continue;                 // long tail: k_grid_query handles it
+        const uint32_t *__restrict__ cell_start = J.cs;
+        const GridRec *__restrict__ srecs = J.srecs;
+        for (uint32_t qi = wave0; qi < count; qi += nwaves) {
+            const double4 qa = *reinterpret_cast<const double4 *>(&J.tail[qi]);   // wave-uniform
+            const double qx = qa.x, qy = qa.y, qz = qa.z;
+            const int qrow = rec_row(qa);
+            const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
+            const int cy = cell_coord(qy, g.org[1], g.inv_h[1], dimy);
+            const int cz = cell_coord(qz, g.org[2], g.inv_h[2], dimz);
+            Best b;
+            b.d = INFINITY;
+            b.idx = 0x7fffffff;
+            bool done = false;
+            for (int r = 1; r <= kMaxRing && !done; ++r) {
+                const int side = 2 * r + 1;
+                if (lane < side * side) {
+                    const int z = cz + lane / side - r, y = cy + lane % side - r;
+                    if (z >= 0 && z < dimz && y >= 0 && y < dimy) {
+                        const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
+                        const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
+                        scan_range<SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
+                    }
                 }
+                double wm = b.d;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) wm = fmin(wm, __shfl_xor(wm, off));
+                int wi = (b.d == wm) ? b.idx : 0x7fffffff;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) wi = min(wi, __shfl_xor(wi, off));
+                b.d = wm;
+                b.idx = wi;
+                done = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, r), b.d);
             }
-            const double m = b.d;
-            double wm = m;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) wm = fmin(wm, __shfl_xor(wm, off));
-            int wi = (m == wm) ? b.idx : 0x7fffffff;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) wi = min(wi, __shfl_xor(wi, off));
-            b.d = wm;
-            b.idx = wi;
-            double L = INFINITY;
-            const double q[3] = {qx, qy, qz};
-            const int c[3] = {cx, cy, cz};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (c[a] - r > 0) L = fmin(L, (q[a] - (g.org[a] + (double)(c[a] - r) * g.h[a])) - g.slack[a]);
-                if (c[a] + r < g.dim[a] - 1) L = fmin(L, ((g.org[a] + (double)(c[a] + r + 1) * g.h[a]) - q[a]) - g.slack[a]);
-            }
-            if (L == INFINITY) done = true;
-            else if (L > 0.0 && b.d < L * L * (1.0 - 0x1.0p-30)) done = true;
-        }
-        if (lane == 0) {
-            if (done) {
-                if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }
-                idx_out[qrow - row_base] = b.idx;
-                d2_out[qrow - row_base] = b.d;
-            } else {
-                double tq = (b.d == INFINITY) ? 1.0e18 : sqrt(b.d) * (1.0 + 0x1.0p-20) + slack32;
-                double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
-                float tf = thr > 3.0e38 ? 3.0e38f : (float)thr;
-                tf = __uint_as_float(__float_as_uint(tf) + 1u);
-                const uint32_t pos = atomicAdd(nflag, 1u);
-                flagged[pos] = (int32_t)(qrow - row_base);
-                flag_thr[pos] = tf;
+            if (lane == 0) {
+                if (done) {
+                    if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }
+                    J.idx_out[qrow - J.row_base] = b.idx;
+                    J.d2_out[qrow - J.row_base] = b.d;
+                } else {
+                    flag_for_rescan(J, qrow, b.d);
+                }
             }
         }
     }
@@ -558,15 +604,24 @@ static double points_per_cell()
 {
     static double k = [] {
         const char *e = getenv("PCCM_GRID_PPC");
-        double v = e ? atof(e) : 2.0;
-        return (v > 0.05 && v < 64.0) ? v : 2.0;
+        double v = e ? atof(e) : 1.5;
+        return (v > 0.05 && v < 64.0) ? v : 1.5;
     }();
     return k;
 }
 
+static bool use_coop()
+{
+    static bool on = [] {
+        const char *e = getenv("PCCM_GRID_COOP");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 // One geometry for BOTH clouds (union bounding box, cell edge from the mean point count): a query's
-// cell in the searched grid is then the cell it was sorted into in its own grid, which is what lets
-// the cooperative kernel work on runs of consecutive cells.
+// cell in the searched cloud's grid is then the cell it was sorted into in its own cloud's grid, which is
+// what lets the cooperative kernel work on runs of consecutive cells.
 static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells)
 {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -627,145 +682,151 @@ static GridGeom geom_of(const Grid &gr)
     return g;
 }
 
-// (re)build the grids of both clouds when either cloud changed or the caches were dropped
-static int ensure_grids(pccm_ctx *ctx)
+// (re)build the combined grid when either cloud changed or the caches were dropped
+static int ensure_grid(pccm_ctx *ctx)
 {
+    Grid &gr = ctx->grid;
     const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
-    bool fresh = true;
-    for (int k = 0; k < 2; ++k)
-        if (ctx->cloud[k].n > 0 && (ctx->grid[k].version != key || ctx->grid[k].n != ctx->cloud[k].n || !ctx->grid[k].recs.p)) fresh = false;
-    if (fresh) return PCCM_OK;
+    if (gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p) return PCCM_OK;
     ProfScope ps(ctx, PCCM_K_GRID_BUILD);
     GridGeom g;
     int64_t ncells;
     choose_geometry(ctx, g, ncells);
-    for (int k = 0; k < 2; ++k) {
-        const Cloud &c = ctx->cloud[k];
-        if (c.n <= 0) continue;
-        Grid &gr = ctx->grid[k];
-        int rc;
-        if ((rc = ensure(ctx, gr.cell_start, (size_t)(ncells + 1) * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(ctx, gr.recs, (size_t)c.n * sizeof(GridRec)))) return rc;
-        if ((rc = sort_by_cell(ctx, c.xyz64, 0, c.n, g, ncells, (uint32_t *)gr.cell_start.p, (GridRec *)gr.recs.p))) return rc;
-        for (int a = 0; a < 3; ++a) {
-            gr.dim[a] = g.dim[a];
-            gr.org[a] = g.org[a];
-            gr.h[a] = g.h[a];
-            gr.inv_h[a] = g.inv_h[a];
-        }
-        gr.ncells = ncells;
-        gr.n = c.n;
-        gr.version = key;
+    const int64_t n0 = ctx->cloud[0].n, n1 = ctx->cloud[1].n;
+    int rc;
+    if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;
+    uint32_t *cs = (uint32_t *)gr.cell_start.p;
+    BuildJobs jobs;
+    jobs.njobs = 2;
+    jobs.j[0] = {ctx->cloud[0].xyz64, 0, n0, cs};
+    jobs.j[1] = {ctx->cloud[1].xyz64, 0, n1, cs + ncells + 1};
+    jobs.total = n0 + n1;
+    if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, cs, 2 * (ncells + 1), (GridRec *)gr.recs.p))) return rc;
+    for (int a = 0; a < 3; ++a) {
+        gr.dim[a] = g.dim[a];
+        gr.org[a] = g.org[a];
+        gr.h[a] = g.h[a];
+        gr.inv_h[a] = g.inv_h[a];
     }
+    gr.ncells = ncells;
+    gr.n[0] = n0;
+    gr.n[1] = n1;
+    gr.key = key;
     return PCCM_OK;
 }
 
-static bool use_coop()
+// Exact 1-NN for `ndirs` directions (LEFT and RIGHT fused into the same launches when both are asked for).
+int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
 {
-    static bool on = [] {
-        const char *e = getenv("PCCM_GRID_COOP");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
-int nn_grid(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, bool self, NNResult &res)
-{
-    const int64_t nq = res.end - res.begin;
-    if (nq <= 0) return PCCM_OK;
-    const int si = (dir == PCCM_DIR_LEFT) ? 1 : 0;      // searched cloud
-    const int ii = (dir == PCCM_DIR_RIGHT) ? 1 : 0;     // iterating cloud
     int rc;
-    if ((rc = ensure_grids(ctx))) return rc;
-    const Grid &sg = ctx->grid[si];
-    const GridGeom g = geom_of(sg);
+    if ((rc = ensure_grid(ctx))) return rc;
+    const Grid &gr = ctx->grid;
+    const GridGeom g = geom_of(gr);
+    const uint32_t *cs_all = (const uint32_t *)gr.cell_start.p;
+    const GridRec *recs_all = (const GridRec *)gr.recs.p;
 
-    const GridRec *qrecs;
-    if (res.begin == 0 && res.end == it.n) {
-        qrecs = (const GridRec *)ctx->grid[ii].recs.p;   // whole cloud: its own cell-sorted records
-    } else {
-        ProfScope ps(ctx, PCCM_K_GRID_BUILD);            // shard: sort its rows by the same cells
-        if ((rc = ensure(ctx, ctx->g_qrecs, (size_t)nq * sizeof(GridRec)))) return rc;
-        if ((rc = sort_by_cell(ctx, it.xyz64, res.begin, nq, g, sg.ncells, nullptr, (GridRec *)ctx->g_qrecs.p))) return rc;
-        qrecs = (const GridRec *)ctx->g_qrecs.p;
-    }
-    if ((rc = ensure(ctx, ctx->flagged, (size_t)nq * sizeof(int32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->flag_thr, (size_t)nq * sizeof(float)))) return rc;
-    if ((rc = ensure(ctx, ctx->g_tail, (size_t)nq * sizeof(GridRec)))) return rc;
-    if ((rc = ensure(ctx, ctx->g_tailcount, 2 * sizeof(uint32_t)))) return rc;
-    PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, sizeof(uint32_t), ctx->stream));
-    const bool exact = it.exact32 && se.exact32;
-    const double maxabs = it.maxabs > se.maxabs ? it.maxabs : se.maxabs;
-    const double slack32 = exact ? 0.0 : maxabs * 0x1.0p-20;
-    const uint32_t *cs = (const uint32_t *)sg.cell_start.p;
-    const GridRec *srecs = (const GridRec *)sg.recs.p;
-    int32_t *flg = (int32_t *)ctx->flagged.p;
-    float *fthr = (float *)ctx->flag_thr.p;
-    {
-        ProfScope ps(ctx, PCCM_K_GRID_QUERY);
-        if (use_coop()) {
-            uint32_t *tailcount = (uint32_t *)ctx->g_tailcount.p;
-            GridRec *tail = (GridRec *)ctx->g_tail.p;
-            PCCM_HIP(hipMemsetAsync(tailcount, 0, sizeof(uint32_t), ctx->stream));
-            const int64_t chunks = (nq + 63) / 64;
-            dim3 grid((unsigned)((chunks + 3) / 4));
-            if (self)
-                hipLaunchKernelGGL((k_grid_query_coop<true>), grid, dim3(256), 0, ctx->stream, qrecs, nq, g, cs, srecs, res.begin,
-                                   slack32, res.idx, res.d2, tail, tailcount);
-            else
-                hipLaunchKernelGGL((k_grid_query_coop<false>), grid, dim3(256), 0, ctx->stream, qrecs, nq, g, cs, srecs, res.begin,
-                                   slack32, res.idx, res.d2, tail, tailcount);
-            // queries ring 1 could not settle: a wave per query when they are few, else the per-thread kernel
-            dim3 wgrid((unsigned)(nq < 4096 ? (nq + 3) / 4 : 1024));
-            if (self)
-                hipLaunchKernelGGL((k_grid_tail_wave<true>), wgrid, dim3(256), 0, ctx->stream, (const GridRec *)tail, tailcount, g, cs,
-                                   srecs, res.begin, slack32, res.idx, res.d2, flg, fthr, res.nflag_dev);
-            else
-                hipLaunchKernelGGL((k_grid_tail_wave<false>), wgrid, dim3(256), 0, ctx->stream, (const GridRec *)tail, tailcount, g, cs,
-                                   srecs, res.begin, slack32, res.idx, res.d2, flg, fthr, res.nflag_dev);
-            dim3 tgrid((unsigned)(nq < 256 * 256 ? (nq + 255) / 256 : 256));
-            if (self)
-                hipLaunchKernelGGL((k_grid_query<true>), tgrid, dim3(256), 0, ctx->stream, (const GridRec *)tail, (int64_t)-1, tailcount, g,
-                                   cs, srecs, res.begin, slack32, res.idx, res.d2, flg, fthr, res.nflag_dev);
-            else
-                hipLaunchKernelGGL((k_grid_query<false>), tgrid, dim3(256), 0, ctx->stream, (const GridRec *)tail, (int64_t)-1, tailcount, g,
-                                   cs, srecs, res.begin, slack32, res.idx, res.d2, flg, fthr, res.nflag_dev);
+    QueryJobs normal, selfj;
+    normal.njobs = 0;
+    selfj.njobs = 0;
+    for (int d = 0; d < ndirs; ++d) {
+        const int dir = dirs[d];
+        NNResult &res = ctx->nn[dir];
+        const int64_t nq = res.end - res.begin;
+        if (nq <= 0) continue;
+        const int si = (dir == PCCM_DIR_LEFT) ? 1 : 0;      // searched cloud
+        const int ii = (dir == PCCM_DIR_RIGHT) ? 1 : 0;     // iterating cloud
+        const Cloud &it = ctx->cloud[ii], &se = ctx->cloud[si];
+        if ((rc = ensure(ctx, res.flagged, (size_t)nq * sizeof(int32_t)))) return rc;
+        if ((rc = ensure(ctx, res.flag_thr, (size_t)nq * sizeof(float)))) return rc;
+        if ((rc = ensure(ctx, res.tail, (size_t)nq * sizeof(GridRec)))) return rc;
+        QueryJob J;
+        if (res.begin == 0 && res.end == it.n) {
+            J.qrecs = recs_all + (ii ? gr.n[0] : 0);       // whole cloud: its own cell-sorted records
         } else {
-            dim3 grid((unsigned)((nq + 255) / 256));
-            if (self)
-                hipLaunchKernelGGL((k_grid_query<true>), grid, dim3(256), 0, ctx->stream, qrecs, nq, (const uint32_t *)nullptr, g, cs,
-                                   srecs, res.begin, slack32, res.idx, res.d2, flg, fthr, res.nflag_dev);
-            else
-                hipLaunchKernelGGL((k_grid_query<false>), grid, dim3(256), 0, ctx->stream, qrecs, nq, (const uint32_t *)nullptr, g, cs,
-                                   srecs, res.begin, slack32, res.idx, res.d2, flg, fthr, res.nflag_dev);
+            ProfScope ps(ctx, PCCM_K_GRID_BUILD);          // shard: sort its rows by the same cells
+            if ((rc = ensure(ctx, res.qrecs, (size_t)nq * sizeof(GridRec)))) return rc;
+            if ((rc = ensure(ctx, ctx->g_hist, (size_t)(gr.ncells + 1) * sizeof(uint32_t)))) return rc;
+            BuildJobs bj;
+            bj.njobs = 1;
+            bj.j[0] = {it.xyz64, res.begin, nq, (uint32_t *)ctx->g_hist.p};
+            bj.j[1] = bj.j[0];
+            bj.total = nq;
+            if ((rc = sort_by_cell(ctx, bj, g, (uint32_t *)ctx->g_hist.p, gr.ncells + 1, (GridRec *)res.qrecs.p))) return rc;
+            J.qrecs = (const GridRec *)res.qrecs.p;
+        }
+        const bool exact = it.exact32 && se.exact32;
+        const double maxabs = it.maxabs > se.maxabs ? it.maxabs : se.maxabs;
+        J.nq = nq;
+        J.nchunks = (nq + 63) / 64;
+        J.cs = cs_all + (si ? gr.ncells + 1 : 0);
+        J.srecs = recs_all;
+        J.row_base = res.begin;
+        J.slack32 = exact ? 0.0 : maxabs * 0x1.0p-20;
+        J.idx_out = res.idx;
+        J.d2_out = res.d2;
+        J.tail = (GridRec *)res.tail.p;
+        J.flagged = (int32_t *)res.flagged.p;
+        J.flag_thr = (float *)res.flag_thr.p;
+        J.counters = res.nflag_dev;                         // [0] flagged, [1] tail length
+        PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
+        QueryJobs &dst = (dir == PCCM_DIR_SELF) ? selfj : normal;
+        dst.j[dst.njobs++] = J;
+        res.stats[1] = 0;
+        res.stats[2] = 0;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        QueryJobs &jobs = pass ? selfj : normal;
+        if (jobs.njobs == 0) continue;
+        if (jobs.njobs == 1) jobs.j[1] = jobs.j[0];
+        const bool self = pass == 1;
+        ProfScope ps(ctx, PCCM_K_GRID_QUERY);
+        int64_t chunks = 0, nqmax = 0;
+        for (int k = 0; k < jobs.njobs; ++k) {
+            chunks += jobs.j[k].nchunks;
+            nqmax = jobs.j[k].nq > nqmax ? jobs.j[k].nq : nqmax;
+        }
+        dim3 tgrid((unsigned)(nqmax < 256 * 256 ? (nqmax + 255) / 256 : 256));
+        if (use_coop()) {
+            dim3 grid((unsigned)((chunks + 3) / 4));
+            dim3 wgrid((unsigned)(nqmax < 4096 ? (nqmax + 3) / 4 : 1024));
+            if (self) {
+                hipLaunchKernelGGL((k_grid_query_coop<true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                hipLaunchKernelGGL((k_grid_tail_wave<true>), wgrid, dim3(256), 0, ctx->stream, jobs, g);
+                hipLaunchKernelGGL((k_grid_query<true>), tgrid, dim3(256), 0, ctx->stream, jobs, g, 1);
+            } else {
+                hipLaunchKernelGGL((k_grid_query_coop<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                hipLaunchKernelGGL((k_grid_tail_wave<false>), wgrid, dim3(256), 0, ctx->stream, jobs, g);
+                hipLaunchKernelGGL((k_grid_query<false>), tgrid, dim3(256), 0, ctx->stream, jobs, g, 1);
+            }
+        } else {
+            dim3 grid((unsigned)((nqmax + 255) / 256));
+            if (self) hipLaunchKernelGGL((k_grid_query<true>), grid, dim3(256), 0, ctx->stream, jobs, g, 0);
+            else hipLaunchKernelGGL((k_grid_query<false>), grid, dim3(256), 0, ctx->stream, jobs, g, 0);
         }
         PCCM_HIP(hipGetLastError());
     }
-    if ((rc = launch_fallback(ctx, it, se, self, res))) return rc;
-    res.stats[1] = 0;
-    res.stats[2] = 0;
+    for (int d = 0; d < ndirs; ++d) {
+        const int dir = dirs[d];
+        NNResult &res = ctx->nn[dir];
+        if (res.end - res.begin <= 0) continue;
+        const int si = (dir == PCCM_DIR_LEFT) ? 1 : 0, ii = (dir == PCCM_DIR_RIGHT) ? 1 : 0;
+        if ((rc = launch_fallback(ctx, ctx->cloud[ii], ctx->cloud[si], dir == PCCM_DIR_SELF, res))) return rc;
+    }
     return PCCM_OK;
 }
 
 void grid_release(pccm_ctx *ctx)
 {
-    for (int k = 0; k < 2; ++k) {
-        if (ctx->grid[k].cell_start.p) (void)hipFree(ctx->grid[k].cell_start.p);
-        if (ctx->grid[k].recs.p) (void)hipFree(ctx->grid[k].recs.p);
-        ctx->grid[k] = Grid();
-    }
-    DevBuf *bufs[] = {&ctx->g_cell_of, &ctx->g_hist, &ctx->g_blocksum, &ctx->g_qrecs, &ctx->g_tail, &ctx->g_tailcount};
+    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.recs, &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
         b->bytes = 0;
     }
+    ctx->grid.key = 0;
 }
 
-void grid_invalidate(pccm_ctx *ctx)
-{
-    ctx->grid[0].version = 0;
-    ctx->grid[1].version = 0;
-}
+void grid_invalidate(pccm_ctx *ctx) { ctx->grid.key = 0; }
 
 }  // namespace pccm

@@ -35,6 +35,11 @@ struct Cloud {
     uint64_t version = 0;       // bumped by pccm_set_cloud (grid caches key on it)
 };
 
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
 struct NNResult {
     bool valid = false;
     int64_t begin = 0, end = 0; // shard rows of the iterating cloud
@@ -42,12 +47,9 @@ struct NNResult {
     double *d2 = nullptr;       // [end-begin]
     int64_t cap = 0;
     int64_t stats[3] = {0, 0, 0};
-    uint32_t *nflag_dev = nullptr;  // device counter of fallback queries of the last run
-};
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
+    uint32_t *nflag_dev = nullptr;  // device counters of the last run: [0] fallback queries, [1] grid tail length
+    DevBuf flagged, flag_thr;       // queries handed to the exact rescan (k2b_fallback) and their thresholds
+    DevBuf tail, qrecs;             // grid engine: unsettled ring-1 queries; cell-sorted rows of a shard
 };
 
 // Uniform grid over one cloud (grid engine): cells in x-fastest order, points counting-sorted by cell.
@@ -56,14 +58,14 @@ struct GridRec {          // 32 B: fp64 position + original row
     int32_t idx, pad;
 };
 
-struct Grid {
-    uint64_t version = 0;          // Cloud::version it was built from (0 = none)
+struct Grid {                    // one geometry, both clouds (grid engine)
+    uint64_t key = 0;              // derived from both Cloud::version values (0 = none)
     int dim[3] = {1, 1, 1};
     double org[3] = {0, 0, 0};
     double h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};   // cell edge per axis
-    int64_t ncells = 0, n = 0;
-    DevBuf cell_start;             // uint32 [ncells + 1]
-    DevBuf recs;                   // GridRec [n]
+    int64_t ncells = 0, n[2] = {0, 0};
+    DevBuf cell_start;             // uint32 [2][ncells + 1]: positions in recs
+    DevBuf recs;                   // GridRec [n[0] + n[1]]: cloud 0's records, then cloud 1's
 };
 
 struct ReduceSlot {            // one enqueued reduction (pccm_reduce_prefetch / pccm_reduce)
@@ -106,9 +108,9 @@ struct pccm_ctx {
     int rank = 0, world = 1;
     pccm::NNResult nn[3];
     // scratch
-    pccm::DevBuf part_b1, part_g, part_b2, flagged, flag_thr, val, unit, stats, staging, counters;
-    pccm::Grid grid[2];
-    pccm::DevBuf g_cell_of, g_hist, g_blocksum, g_qrecs, g_tail, g_tailcount;   // grid-engine scratch
+    pccm::DevBuf part_b1, part_g, part_b2, val, unit, stats, staging, counters;
+    pccm::Grid grid;
+    pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum;   // grid-engine scratch
     std::vector<double> host_unit;
     pccm::ReduceSlot slots[8];
     uint64_t nn_gen[3] = {1, 1, 1};
@@ -157,7 +159,7 @@ int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, 
 // brute-force engine: fills res.idx / res.d2 for rows [res.begin, res.end) of `it` searched in `se`
 int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
 // grid engine
-int nn_grid(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, bool self, NNResult &res);
+int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs);
 void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
 int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
