@@ -143,8 +143,12 @@ int pccm_point_metric(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
  */
 int64_t pccm_xvec_len(int64_t n_iter);
 int pccm_reduce_prefetch(pccm_ctx *ctx, int dir, int metric, int normal_mode);
+/* n <= 8 columns at once: one kernel evaluates every point-to-plane column, one kernel reduces all of them. */
+int pccm_reduce_prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes);
 int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xvec, double *minmax);
 int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum);
+/* Unsharded shortcut (world = 1): out = {np.sum, np.min, np.max} of the whole column in one call. */
+int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, double out[3]);
 
 /* Forget the search structures derived from the clouds (the grid engine's cell-sorted copies,
  * the analogue of the KD-trees CloudPair.__init__ builds at cloud_pair.py:65), so that the next

@@ -28,7 +28,8 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy",
     "pccm_set_cloud", "pccm_set_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
-    "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce", "pccm_finish_sum",
+    "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
+    "pccm_reduce_total",
     "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
@@ -77,7 +78,10 @@ def load() -> ctypes.CDLL:
     lib.pccm_xvec_len.restype = i64
     lib.pccm_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.pccm_reduce_prefetch.argtypes = [vp, i32, i32, i32]
+    ip = ctypes.POINTER(i32)
+    lib.pccm_reduce_prefetch_many.argtypes = [vp, i32, ip, ip, ip]
     lib.pccm_finish_sum.argtypes = [vp, i64, dp]
+    lib.pccm_reduce_total.argtypes = [vp, i32, i32, i32, dp]
     lib.pccm_sync.argtypes = [vp]
     lib.pccm_drop_caches.argtypes = [vp]
     lib.pccm_graph_begin.argtypes = [vp]
@@ -229,6 +233,17 @@ class Engine:
         """Enqueue a reduction without waiting; a later reduce() with the same arguments consumes it."""
         _check(self._lib.pccm_reduce_prefetch(self._ctx, int(direction), int(metric), NORMAL_MODES[normal_mode]))
 
+    def reduce_prefetch_many(self, requests, normal_mode: str = "row") -> None:
+        """``requests``: up to 8 ``(direction, metric)`` pairs, evaluated and reduced by two launches in all."""
+        k = len(requests)
+        if k == 0:
+            return
+        arr = ctypes.c_int * k
+        dirs = arr(*[int(r[0]) for r in requests])
+        mets = arr(*[int(r[1]) for r in requests])
+        modes = arr(*([NORMAL_MODES[normal_mode]] * k))
+        _check(self._lib.pccm_reduce_prefetch_many(self._ctx, k, dirs, mets, modes))
+
     def reduce(self, direction: int, metric: int, normal_mode: str = "row"):
         """-> (xvec, min, max) of this shard; see pccm_reduce() in include/pccm.h."""
         xvec = np.empty(xvec_len(self.n_iter(direction)), dtype=np.float64)
@@ -238,6 +253,12 @@ class Engine:
         return xvec, mm[0], mm[1]
 
     finish_sum = staticmethod(finish_sum)
+
+    def reduce_total(self, direction: int, metric: int, normal_mode: str = "row"):
+        """-> (sum, min, max) of the whole column; only when the context is not sharded."""
+        out = (ctypes.c_double * 3)()
+        _check(self._lib.pccm_reduce_total(self._ctx, int(direction), int(metric), NORMAL_MODES[normal_mode], out))
+        return np.float64(out[0]), np.float64(out[1]), np.float64(out[2])
 
     # -- housekeeping -------------------------------------------------------------------------
     def sync(self) -> None:

@@ -129,12 +129,15 @@ class DeviceColumn(_DeviceArray):
         """(sum, min, max) of the whole column: fused on the GPU, exchanged across ranks."""
         if self._red is None:
             p = self._pair
-            xvec, mn, mx = p._engine.reduce(self._dir, self._METRIC[self._kind], p.normal_index)
-            if p._coll.sharded:
-                xvec = p._coll.allreduce(xvec, "sum")
-                ext = p._coll.allreduce(np.array([mx, -mn]), "max")
-                mx, mn = ext[0], -ext[1]
-            total = p._engine.finish_sum(xvec, self.shape[0])
+            if not p._coll.sharded and hasattr(p._engine, "reduce_total"):
+                total, mn, mx = p._engine.reduce_total(self._dir, self._METRIC[self._kind], p.normal_index)
+            else:
+                xvec, mn, mx = p._engine.reduce(self._dir, self._METRIC[self._kind], p.normal_index)
+                if p._coll.sharded:
+                    xvec = p._coll.allreduce(xvec, "sum")
+                    ext = p._coll.allreduce(np.array([mx, -mn]), "max")
+                    mx, mn = ext[0], -ext[1]
+                total = p._engine.finish_sum(xvec, self.shape[0])
             if self._kind == "boundary":          # sqrt is monotonic: min/max commute with it
                 mn, mx, total = np.sqrt(mn), np.sqrt(mx), None
             self._red = (total, np.float64(mn), np.float64(mx))
@@ -334,22 +337,28 @@ class CloudPair:
                 eng.graph_destroy(self._graph_id)             # a different report: capture anew next time
                 self._graph_id = None
             self._last_wanted = wanted
+        requests = []
         for item in wanted:
             if item == "boundary":
                 if not self._self_done:
                     eng.nn(nat.DIR_SELF, self.nn_engine)
                     self._self_done = True
-                eng.reduce_prefetch(nat.DIR_SELF, nat.METRIC_D1, self.normal_index)
+                requests.append((nat.DIR_SELF, nat.METRIC_D1))
                 continue
             is_left, p2p = item
             direction = nat.DIR_LEFT if is_left else nat.DIR_RIGHT
             if not p2p:
-                eng.reduce_prefetch(direction, nat.METRIC_D1, self.normal_index)
+                requests.append((direction, nat.METRIC_D1))
             elif _has_normals(self.clouds[1 if is_left else 0]):
-                try:
-                    eng.reduce_prefetch(direction, nat.METRIC_D2, self.normal_index)
-                except IndexError:
-                    pass          # row-indexed normals out of range: surfaces where the reference raises
+                n_other = len(self.clouds[1 if is_left else 0].normals)
+                if self.normal_index == "row" and eng.shard_range(direction)[1] > n_other:
+                    continue      # row-indexed normals out of range: surfaces where the reference raises
+                requests.append((direction, nat.METRIC_D2))
+        if hasattr(eng, "reduce_prefetch_many"):
+            eng.reduce_prefetch_many(requests[:8], self.normal_index)
+        else:
+            for direction, metric in requests:
+                eng.reduce_prefetch(direction, metric, self.normal_index)
 
     # -- fused projection used by metric.ErrorVector ------------------------------------------------
     def point_to_plane_column(self, is_left: bool) -> DeviceColumn:

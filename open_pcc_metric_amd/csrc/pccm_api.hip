@@ -567,14 +567,29 @@ int64_t pccm_xvec_len(int64_t n_iter)
 // the unit arrays and of the shard's raw tail values into pinned host memory -> event.  pccm_reduce()
 // consumes a slot (enqueuing it first when nobody prefetched it), so a caller that prefetches every
 // column it will need waits for the GPU once per step instead of once per column.
-static int slot_enqueue(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int normal_mode)
+// bookkeeping + buffers of one slot; the kernels are launched for all new slots together (slots_launch)
+static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int normal_mode, PointJobs &pj, UnitJobs &uj)
 {
-    const double *dev;
-    int64_t ns;
-    const Cloud *it;
+    const Cloud *it, *se;
     NNResult *res;
-    int rc = metric_on_device(ctx, dir, metric, normal_mode, &dev, &ns, &it, &res, &s.val);
+    int rc = need_nn(ctx, dir, &it, &se, &res);
     if (rc) return rc;
+    const int64_t ns = res->end - res->begin;
+    const double *dev = res->d2;
+    if (metric != PCCM_METRIC_D1) {
+        if (metric != PCCM_METRIC_D2 && metric != PCCM_METRIC_PROJ) return fail(PCCM_E_ARG, "bad metric %d", metric);
+        if (dir == PCCM_DIR_SELF) return fail(PCCM_E_ARG, "point-to-plane is not defined for the self search");
+        if ((rc = check_normals(*se, *res, normal_mode))) return rc;
+        if ((rc = ensure(ctx, s.val, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
+        dev = (const double *)s.val.p;
+        if (ns > 0) {
+            PointJob &P = pj.j[pj.njobs];
+            P.q64 = it->xyz64; P.r64 = se->xyz64; P.nrm = se->nrm64; P.idx = res->idx;
+            P.q_begin = res->begin; P.metric = metric; P.normal_mode = normal_mode; P.val = (double *)s.val.p;
+            pj.off[pj.njobs + 1] = pj.off[pj.njobs] + ns;
+            pj.njobs++;
+        }
+    }
     s.dir = dir; s.metric = metric; s.mode = normal_mode;
     s.gen = ctx->nn_gen[dir];
     s.n_iter = it->n; s.begin = res->begin; s.end = res->end;
@@ -596,24 +611,15 @@ static int slot_enqueue(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     }
     if (!s.ev) PCCM_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
     if (s.nunits > 0) {
-        if ((rc = ensure(ctx, s.unit, (size_t)s.nunits * 3 * sizeof(double)))) return rc;
-        if ((rc = launch_unit_reduce(ctx, dev, ns, (double *)s.unit.p, s.nunits))) return rc;
-        PCCM_HIP(hipMemcpyAsync(s.host, s.unit.p, (size_t)s.nunits * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (s.tail_n > 0)
-            PCCM_HIP(hipMemcpyAsync(s.host + 3 * s.nunits, dev + (s.t0 - res->begin), (size_t)s.tail_n * sizeof(double),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+        UnitJob &U = uj.j[uj.njobs];
+        U.val = dev; U.ns = ns; U.nunits = s.nunits;
+        U.tail_first = s.t0 - res->begin; U.tail_n = s.tail_n;
+        U.out = s.host;
+        const int64_t lanes = (s.nunits * 8 + 255) / 256 * 256;
+        uj.uoff[uj.njobs + 1] = uj.uoff[uj.njobs] + lanes;
+        uj.toff[uj.njobs + 1] = uj.toff[uj.njobs] + s.tail_n;
+        uj.njobs++;
     }
-    if (ctx->capturing) {
-        GraphOp op;
-        op.kind = 2;
-        op.dir = dir;
-        op.slot = (int)(&s - ctx->slots);
-        op.snap = s;
-        ctx->cap_ops.push_back(op);
-    } else {
-        PCCM_HIP(hipEventRecord(s.ev, ctx->stream));
-    }
-    s.pending = true;
     return PCCM_OK;
 }
 
@@ -633,15 +639,51 @@ static ReduceSlot *slot_free(pccm_ctx *ctx)
     return &ctx->slots[0];
 }
 
-int pccm_reduce_prefetch(pccm_ctx *ctx, int dir, int metric, int normal_mode)
+int pccm_reduce_prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes)
 {
     CHECK_CTX(ctx);
-    if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
-    if (slot_find(ctx, dir, metric, normal_mode)) return PCCM_OK;
-    ReduceSlot *s = slot_free(ctx);
-    if (s->pending && !ctx->capturing) PCCM_HIP(hipEventSynchronize(s->ev));
-    s->pending = false;
-    return slot_enqueue(ctx, *s, dir, metric, normal_mode);
+    if (n < 0 || n > 8 || (n > 0 && (!dirs || !metrics || !normal_modes))) return fail(PCCM_E_ARG, "1..8 requests expected");
+    PointJobs pj;
+    UnitJobs uj;
+    pj.njobs = 0; pj.off[0] = 0;
+    uj.njobs = 0; uj.uoff[0] = 0; uj.toff[0] = 0;
+    ReduceSlot *fresh[8];
+    int nfresh = 0;
+    for (int k = 0; k < n; ++k) {
+        if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
+        if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k])) continue;
+        if (pj.njobs >= 4 && metrics[k] != PCCM_METRIC_D1) return fail(PCCM_E_ARG, "at most four point-to-plane columns per call");
+        ReduceSlot *s = slot_free(ctx);
+        if (s->pending && !ctx->capturing) PCCM_HIP(hipEventSynchronize(s->ev));
+        s->pending = false;
+        int rc = slot_prepare(ctx, *s, dirs[k], metrics[k], normal_modes[k], pj, uj);
+        if (rc) return rc;
+        s->pending = true;                 // so that slot_free/slot_find see it while the batch is assembled
+        fresh[nfresh++] = s;
+    }
+    if (nfresh == 0) return PCCM_OK;
+    int rc;
+    if ((rc = launch_point_jobs(ctx, pj))) return rc;
+    if ((rc = launch_unit_jobs(ctx, uj))) return rc;
+    for (int k = 0; k < nfresh; ++k) {
+        ReduceSlot &s = *fresh[k];
+        if (ctx->capturing) {
+            GraphOp op;
+            op.kind = 2;
+            op.dir = s.dir;
+            op.slot = (int)(&s - ctx->slots);
+            op.snap = s;
+            ctx->cap_ops.push_back(op);
+        } else {
+            PCCM_HIP(hipEventRecord(s.ev, ctx->stream));
+        }
+    }
+    return PCCM_OK;
+}
+
+int pccm_reduce_prefetch(pccm_ctx *ctx, int dir, int metric, int normal_mode)
+{
+    return pccm_reduce_prefetch_many(ctx, 1, &dir, &metric, &normal_mode);
 }
 
 int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xvec, double *minmax)
@@ -701,6 +743,49 @@ int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum)
         s = first ? ts : s + ts;
     }
     *sum = s;
+    return PCCM_OK;
+}
+
+int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, double out[3])
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (!out) return fail(PCCM_E_ARG, "null pointer");
+    if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
+    if (ctx->world != 1) return fail(PCCM_E_STATE, "pccm_reduce_total needs the whole column on this GPU (world = 1)");
+    ReduceSlot *s = slot_find(ctx, dir, metric, normal_mode);
+    if (!s) {
+        int rc = pccm_reduce_prefetch(ctx, dir, metric, normal_mode);
+        if (rc) return rc;
+        s = slot_find(ctx, dir, metric, normal_mode);
+        if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
+    }
+    PCCM_HIP(hipEventSynchronize(s->ev));
+    s->pending = false;
+    const int64_t n = s->n_iter, nunits = s->nunits;
+    const int64_t nfull = n / kChunk;
+    const int lpc = kChunk / kLeaf;
+    const double *usum = s->host, *umin = usum + nunits, *umax = usum + 2 * nunits;
+    // np.sum: chunks of 8192 rows in sequence, each chunk = NumPy's pairwise tree over its 64 leaf sums
+    double total = 0.0;
+    bool first = true;
+    for (int64_t c = 0; c < nfull; ++c) {
+        const double cs = leaf_tree(usum + c * lpc, lpc);
+        total = first ? cs : total + cs;
+        first = false;
+    }
+    if (s->tail_n > 0) {
+        const double ts = np_pairwise_sum(s->host + 3 * nunits, s->tail_n);
+        total = first ? ts : total + ts;
+    }
+    double mn = INFINITY, mx = -INFINITY;
+    for (int64_t u = 0; u < nunits; ++u) {
+        mn = umin[u] < mn ? umin[u] : mn;
+        mx = umax[u] > mx ? umax[u] : mx;
+    }
+    out[0] = total;
+    out[1] = mn;
+    out[2] = mx;
     return PCCM_OK;
 }
 

@@ -164,6 +164,33 @@ void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
 int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
 
+struct PointJob {               // one D2 / PROJ column (k_point_jobs)
+    const double *q64, *r64, *nrm;
+    const int32_t *idx;
+    int64_t q_begin;
+    int metric, normal_mode;
+    double *val;
+};
+struct PointJobs {
+    PointJob j[4];
+    int njobs;
+    int64_t off[5];             // prefix sums of the jobs' row counts
+};
+struct UnitJob {                // one column to reduce (k_unit_jobs)
+    const double *val;
+    int64_t ns, nunits;
+    int64_t tail_first, tail_n; // rows [tail_first, tail_first + tail_n) are copied out raw
+    double *out;                // pinned host memory: [3][nunits] sums/min/max, then tail_n raw values
+};
+struct UnitJobs {
+    UnitJob j[8];
+    int njobs;
+    int64_t uoff[9];            // prefix sums of 8 * nunits, each rounded up to a multiple of 256
+    int64_t toff[9];            // prefix sums of tail_n
+};
+int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs);
+int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs);
+
 int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,
                         int normal_mode, double *out_val /*[ns]*/, double *out_err /*[ns][3] or null*/);
 // per-unit (128 rows) sums/min/max of val[0..ns): unit_out = [3][nunits] (sum, min, max)

@@ -218,6 +218,113 @@ int launch_unit_reduce(pccm_ctx *ctx, const double *val, int64_t ns, double *uni
     return PCCM_OK;
 }
 
+// ---- batched forms: several columns per launch, results written straight into pinned host memory ------
+// A report needs up to four columns (D1/D2 x left/right).  One k_point_jobs launch evaluates all D2
+// columns, one k_unit_jobs launch reduces all columns and stores the per-unit sums/min/max and the raw
+// tail values directly into the slots' pinned host buffers (device-visible), so there is no copy node
+// and no extra launch per column.
+__global__ __launch_bounds__(256) void k_point_jobs(PointJobs jobs)
+{
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i0 >= jobs.off[jobs.njobs]) return;
+    int jb = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < jobs.njobs && i0 >= jobs.off[k]) jb = k;
+    const PointJob &J = jobs.j[jb];
+    const int64_t i = i0 - jobs.off[jb];
+    const int64_t gi = J.q_begin + i;
+    const int64_t j = J.idx[i];
+    const double ex = __dsub_rn(J.q64[3 * gi], J.r64[3 * j]);
+    const double ey = __dsub_rn(J.q64[3 * gi + 1], J.r64[3 * j + 1]);
+    const double ez = __dsub_rn(J.q64[3 * gi + 2], J.r64[3 * j + 2]);
+    const int64_t k = (J.normal_mode == PCCM_NORMAL_ROW) ? gi : j;
+    double p = __dmul_rn(ex, J.nrm[3 * k]);
+    p = __fma_rn(ey, J.nrm[3 * k + 1], p);
+    p = __fma_rn(ez, J.nrm[3 * k + 2], p);
+    J.val[i] = (J.metric == PCCM_METRIC_PROJ) ? p : __dmul_rn(p, p);
+}
+
+int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs)
+{
+    const int64_t total = jobs.off[jobs.njobs];
+    if (total <= 0) return PCCM_OK;
+    ProfScope ps(ctx, PCCM_K_POINT);
+    hipLaunchKernelGGL(k_point_jobs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, jobs);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t unit_threads = jobs.uoff[jobs.njobs];
+    if (t < unit_threads) {
+        int jb = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < jobs.njobs && t >= jobs.uoff[k]) jb = k;
+        const UnitJob &J = jobs.j[jb];
+        const int64_t u = (t - jobs.uoff[jb]) >> 3;
+        const int k = threadIdx.x & 7;
+        if (u >= J.nunits) return;                 // padding lanes of a job (whole 8-lane groups)
+        const double *__restrict__ val = J.val;
+        const int64_t base = u * kLeaf;
+        const int64_t cnt = (J.ns - base < kLeaf) ? J.ns - base : kLeaf;
+        double r = 0.0, mn = INFINITY, mx = -INFINITY;
+        if (cnt == kLeaf) {
+            r = val[base + k];
+            mn = mx = r;
+#pragma unroll
+            for (int j = 1; j < kLeaf / 8; ++j) {
+                double v = val[base + 8 * j + k];
+                r = __dadd_rn(r, v);
+                mn = fmin(mn, v);
+                mx = fmax(mx, v);
+            }
+        } else {
+            for (int64_t e = k; e < cnt; e += 8) {
+                double v = val[base + e];
+                r = __dadd_rn(r, v);
+                mn = fmin(mn, v);
+                mx = fmax(mx, v);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            r = __dadd_rn(r, __shfl_xor(r, off));
+            mn = fmin(mn, __shfl_xor(mn, off));
+            mx = fmax(mx, __shfl_xor(mx, off));
+        }
+        if (k == 0) {
+            J.out[u] = r;
+            J.out[J.nunits + u] = mn;
+            J.out[2 * J.nunits + u] = mx;
+        }
+        return;
+    }
+    // raw values of the last, partial 8192-row chunk (NumPy sums them with its own tree on the host)
+    const int64_t c = t - unit_threads;
+    if (c >= jobs.toff[jobs.njobs]) return;
+    int jb = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < jobs.njobs && c >= jobs.toff[k]) jb = k;
+    const UnitJob &J = jobs.j[jb];
+    const int64_t e = c - jobs.toff[jb];
+    J.out[3 * J.nunits + e] = J.val[J.tail_first + e];
+}
+
+int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
+{
+    const int64_t total = jobs.uoff[jobs.njobs] + jobs.toff[jobs.njobs];
+    if (total <= 0) return PCCM_OK;
+    ProfScope ps(ctx, PCCM_K_REDUCE);
+    hipLaunchKernelGGL(k_unit_jobs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, jobs);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
 // NumPy's DOUBLE pairwise sum over one contiguous run of at most kChunk values.
 double np_pairwise_sum(const double *a, int64_t n)
 {
