@@ -411,10 +411,17 @@ constexpr float kBigF = 3.0e38f;
 template <bool SELF>
 __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeom g)
 {
-    __shared__ float lx[4][kCap], ly[4][kCap], lz[4][kCap];
-    __shared__ int lrow[SELF ? 4 : 1][SELF ? kCap : 1];
+    __shared__ float lx[4][kCap + 1], ly[4][kCap + 1], lz[4][kCap + 1];
+    __shared__ int lrow[SELF ? 4 : 1][SELF ? kCap + 1 : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int64_t chunk = (int64_t)blockIdx.x * 4 + w;
+    // XCD-aware order: workgroups b, b+8, b+16, ... share an XCD (and its 4 MB L2), so give every XCD one
+    // contiguous eighth of the cell-sorted chunk list = one slab of the grid.  The nine x-runs a chunk
+    // stages are shared with the chunks of the neighbouring rows; with this mapping those run on the same
+    // XCD and hit its L2 instead of each XCD pulling its own copy from the Infinity Cache.  Speed only.
+    const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t bq = nblk >> 3, br = nblk & 7u;
+    const uint32_t vb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + slot;
+    int64_t chunk = (int64_t)vb * 4 + w;
     const int jb = (jobs.njobs > 1 && chunk >= jobs.j[0].nchunks) ? 1 : 0;     // wave-uniform
     if (jb) chunk -= jobs.j[0].nchunks;
     const QueryJob &J = jobs.j[jb];
@@ -492,17 +499,34 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
                     const uint32_t fa = rs[k], fb = rs[k] + rl[k];
                     const uint32_t lo = fa > W0 ? fa : W0, hi = fb < W1 ? fb : W1;
                     const uint32_t delta = S[k] - off[k];                         // flat position -> record in srecs
-                    for (uint32_t f = lo; f < hi; ++f) {
+                    // two candidates per trip: their LDS reads are issued together, so the LDS latency is
+                    // paid once per pair (slot o+1 always exists: the arrays carry one spare element)
+                    for (uint32_t f = lo; f < hi; f += 2) {
                         const uint32_t o = f - W0;
-                        const float dx = fx - lx[w][o], dy = fy - ly[w][o], dz = fz - lz[w][o];
-                        float d = dx * dx;
-                        d = __builtin_fmaf(dy, dy, d);
-                        d = __builtin_fmaf(dz, dz, d);
-                        if (SELF) d = (lrow[w][o] == qrow) ? kBigF : d;
-                        second = __builtin_amdgcn_fmed3f(best, second, d);
-                        const bool upd = d < best;
-                        best = upd ? d : best;
-                        bestpos = upd ? f + delta : bestpos;
+                        const bool two = f + 1 < hi;
+                        const float x0 = lx[w][o], x1 = lx[w][o + 1];
+                        const float y0 = ly[w][o], y1 = ly[w][o + 1];
+                        const float z0 = lz[w][o], z1 = lz[w][o + 1];
+                        const float ax = fx - x0, ay = fy - y0, az = fz - z0;
+                        const float bx = fx - x1, by = fy - y1, bz = fz - z1;
+                        float d0 = ax * ax, d1 = bx * bx;
+                        d0 = __builtin_fmaf(ay, ay, d0);
+                        d1 = __builtin_fmaf(by, by, d1);
+                        d0 = __builtin_fmaf(az, az, d0);
+                        d1 = __builtin_fmaf(bz, bz, d1);
+                        if (SELF) {
+                            d0 = (lrow[w][o] == qrow) ? kBigF : d0;
+                            d1 = (lrow[w][o + 1] == qrow) ? kBigF : d1;
+                        }
+                        d1 = two ? d1 : kBigF;
+                        second = __builtin_amdgcn_fmed3f(best, second, d0);
+                        const bool u0 = d0 < best;
+                        best = u0 ? d0 : best;
+                        bestpos = u0 ? f + delta : bestpos;
+                        second = __builtin_amdgcn_fmed3f(best, second, d1);
+                        const bool u1 = d1 < best;
+                        best = u1 ? d1 : best;
+                        bestpos = u1 ? f + 1 + delta : bestpos;
                     }
                 }
             }
@@ -786,7 +810,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
             chunks += jobs.j[k].nchunks;
             nqmax = jobs.j[k].nq > nqmax ? jobs.j[k].nq : nqmax;
         }
-        dim3 tgrid((unsigned)(nqmax < 256 * 256 ? (nqmax + 255) / 256 : 256));
+        dim3 tgrid((unsigned)((nqmax + 255) / 256));     // long tails need the whole grid; idle blocks just exit
         if (use_coop()) {
             dim3 grid((unsigned)((chunks + 3) / 4));
             dim3 wgrid((unsigned)(nqmax < 4096 ? (nqmax + 3) / 4 : 1024));
