@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "brute", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -89,10 +91,14 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: open_pcc_metric_amd has no CPU path")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     group = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
         group = dist.group.WORLD
 
     n = args.points
@@ -138,7 +144,7 @@ def main():
         prof_leg = f"HIP events over {min(args.steps, 10)} eager steps issued right after the timed hipGraph region"
     eng.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -131,12 +131,10 @@ class DeviceColumn(_DeviceArray):
             p = self._pair
             if not p._coll.sharded and hasattr(p._engine, "reduce_total"):
                 total, mn, mx = p._engine.reduce_total(self._dir, self._METRIC[self._kind], p.normal_index)
+            elif p._coll.sharded:
+                total, mn, mx = p._sharded_reduction(self._dir, self._METRIC[self._kind])
             else:
                 xvec, mn, mx = p._engine.reduce(self._dir, self._METRIC[self._kind], p.normal_index)
-                if p._coll.sharded:
-                    xvec = p._coll.allreduce(xvec, "sum")
-                    ext = p._coll.allreduce(np.array([mx, -mn]), "max")
-                    mx, mn = ext[0], -ext[1]
                 total = p._engine.finish_sum(xvec, self.shape[0])
             if self._kind == "boundary":          # sqrt is monotonic: min/max commute with it
                 mn, mx, total = np.sqrt(mn), np.sqrt(mx), None
@@ -195,6 +193,7 @@ class CloudPair:
         self.normal_index = normal_index
         self.nn_engine = nn_engine
         self._use_graph = bool(use_graph)
+        self._xchg, self._xchg_wanted = {}, []
         self._graph_id = None
         self._last_wanted = None
         self._extent = None if extent is None else np.asarray(extent, dtype=np.float64)
@@ -217,6 +216,7 @@ class CloudPair:
         (cloud_pair.py:67-78 does this once, eagerly, in the constructor) and drop cached results."""
         eng = self._engine
         self._idx_cache = {}
+        self._xchg = {}
         if self._use_graph and self._last_wanted is not None and hasattr(eng, "graph_begin"):
             wants_self = "boundary" in self._last_wanted
             if self._graph_id is not None:
@@ -257,6 +257,34 @@ class CloudPair:
         n = self._engine.n_iter(direction)
         counts = [_shard_bounds(n, r, self._coll.world) for r in range(self._coll.world)]
         return self._coll.allgather_rows(local, [e - b for b, e in counts])
+
+    def _sharded_reduction(self, direction: int, metric: int):
+        """(sum, min, max) of a whole column when the query axis is sharded.
+
+        The exchange vectors of ALL columns the current report asked for (prefetch_reductions) travel in
+        one all-reduce(SUM) and their extrema in one all-reduce(MAX): two collectives per report, however
+        many columns it has.  Every rank calls this with the same requests in the same order."""
+        key = (direction, metric)
+        if key not in self._xchg:
+            eng, coll = self._engine, self._coll
+            batch = [k for k in self._xchg_wanted if k not in self._xchg]
+            if key not in batch:
+                batch.append(key)
+            parts, ext = [], []
+            for d, m in batch:
+                xvec, mn, mx = eng.reduce(d, m, self.normal_index)
+                parts.append(xvec)
+                ext += [mx, -mn]
+            summed = coll.allreduce(np.concatenate(parts), "sum")        # x + 0 is exact: bitwise assembly
+            ext = coll.allreduce(np.asarray(ext, dtype=np.float64), "max")
+            pos = 0
+            for i, (d, m) in enumerate(batch):
+                n = eng.n_iter(d)
+                ln = len(parts[i])
+                self._xchg[(d, m)] = (eng.finish_sum(summed[pos:pos + ln], n), np.float64(-ext[2 * i + 1]),
+                                      np.float64(ext[2 * i]))
+                pos += ln
+        return self._xchg[key]
 
     def _neighbour_index(self, direction: int) -> np.ndarray:
         if direction not in self._idx_cache:
@@ -329,10 +357,9 @@ class CloudPair:
         that the host waits for the GPU once per report instead of once per column.  Purely an
         optimisation: columns that were not prefetched are reduced on demand."""
         eng = self._engine
-        if not hasattr(eng, "reduce_prefetch"):
-            return
+        can_prefetch = hasattr(eng, "reduce_prefetch")
         wanted = list(wanted)
-        if _remember:
+        if _remember and can_prefetch:
             if self._last_wanted is not None and wanted != self._last_wanted and self._graph_id is not None:
                 eng.graph_destroy(self._graph_id)             # a different report: capture anew next time
                 self._graph_id = None
@@ -354,6 +381,9 @@ class CloudPair:
                 if self.normal_index == "row" and eng.shard_range(direction)[1] > n_other:
                     continue      # row-indexed normals out of range: surfaces where the reference raises
                 requests.append((direction, nat.METRIC_D2))
+        self._xchg_wanted = list(requests)
+        if not can_prefetch:
+            return
         if hasattr(eng, "reduce_prefetch_many"):
             eng.reduce_prefetch_many(requests[:8], self.normal_index)
         else:

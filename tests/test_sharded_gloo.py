@@ -36,7 +36,8 @@ ev = np.asarray(pair.get_left_error_vector())
 out = {"rank": dist.get_rank(), "shard": pair._engine.shard_range(0),
        "rows": [[list(map(str, k)), float(v).hex()] for k, v in res.items()],
        "col_sum": float(np.sum(col)).hex(), "col_len": len(col), "ev_sum": float(np.sum(ev)).hex()}
-print("RESULT " + json.dumps(out), flush=True)
+with open(os.path.join(os.environ["PCCM_OUT"], f"rank{dist.get_rank()}.json"), "w") as fh:
+    json.dump(out, fh)
 dist.destroy_process_group()
 '''
 
@@ -52,7 +53,7 @@ def test_two_gloo_ranks_match_single_process(tmp_path, n):
 
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1", PCCM_OUT=str(tmp_path))
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -61,7 +62,7 @@ def test_two_gloo_ranks_match_single_process(tmp_path, n):
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
-    outs = [json.loads(line.split("RESULT ", 1)[1]) for line in proc.stdout.splitlines() if "RESULT " in line]
+    outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in (0, 1)]
     assert sorted(o["rank"] for o in outs) == [0, 1]
     assert outs[0]["rows"] == outs[1]["rows"]                      # both ranks hold the full result
     shards = sorted(tuple(o["shard"]) for o in outs)
