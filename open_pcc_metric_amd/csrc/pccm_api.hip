@@ -217,7 +217,7 @@ int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
         ctx->own_stream = true;
     }
     int rc = ensure(ctx, ctx->counters, 6 * sizeof(uint32_t));
-    if (!rc) rc = ensure(ctx, ctx->stats, 9 * sizeof(unsigned long long));
+    if (!rc) rc = ensure(ctx, ctx->stats, 10 * sizeof(unsigned long long));
     if (rc) {
         pccm_ctx_destroy(ctx);
         return rc;
@@ -277,11 +277,11 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     int rc = upload(ctx, xyz, (size_t)n * 3 * esz, on_device, &dsrc);
     if (rc) return rc;
     unsigned long long *stats = (unsigned long long *)ctx->stats.p;
-    PCCM_HIP(hipMemsetAsync(stats, 0, 9 * sizeof(unsigned long long), ctx->stream));
+    PCCM_HIP(hipMemsetAsync(stats, 0, 10 * sizeof(unsigned long long), ctx->stream));
     PCCM_HIP(hipMemsetAsync(stats + 3, 0xff, 3 * sizeof(unsigned long long), ctx->stream));
     rc = launch_ingest_points(ctx, dsrc, dtype, n, n_pad, c.xyz32, c.xyz64, stats);
     if (rc) return rc;
-    unsigned long long h[9];
+    unsigned long long h[10];
     PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     double maxabs;
@@ -294,6 +294,7 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     c.n_pad = n_pad;
     c.maxabs = maxabs;
     c.exact32 = (h[1] == 0);
+    c.all_int = (h[1] == 0 && h[9] == 0);
     for (int k = 0; k < 3; ++k) {
         auto unkey = [](unsigned long long b) {
             b = (b >> 63) ? (b & 0x7fffffffffffffffull) : ~b;

@@ -231,7 +231,7 @@ struct QueryJob {
     const uint32_t *cs;         // searched cloud's cell starts (positions in srecs)
     const GridRec *srecs;       // combined record array
     int64_t row_base;           // first row of the shard (outputs are indexed row - row_base)
-    double slack32;             // fp32 rounding slack of inexact inputs (see pccm_brute.hip)
+    double slack32;             // fp32 rounding slack of inexact inputs (see pccm_brute.hip); 0 = both clouds fp32-exact
     int32_t *idx_out;
     double *d2_out;
     GridRec *tail;              // queries ring 1 could not settle
@@ -402,13 +402,15 @@ __global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g, 
 //      tracking best d32, its record position and the second-best d32 -- no fp64, no branches,
 //   4. certifies like k2_refine: if the second-best d32 is above thr(best d32) the fp32 winner is the
 //      unique fp64 winner, whose exact d2 is then computed once from its fp64 record.
-// Queries that cannot be certified (near ties, exact ties on lattices) or whose ring-1 result does not
-// satisfy the stop rule go to `tail`.
+// Queries that cannot be certified (near ties) or whose ring-1 result does not satisfy the stop rule go
+// to `tail`.  TIES: instantiation for voxelised content (integer coordinates, where exact ties are the
+// rule): uncertified queries are settled in place with fp64 arithmetic over the staged candidates.  It
+// needs more registers, so it is only used when the ingest saw integer-valued, fp32-exact clouds.
 constexpr int kCap = 384;         // fp32 records staged per wave (4.5 KB); more -> several windows
 constexpr int kSegWidth = 61;     // + 3 bounds = 64 lanes
 constexpr float kBigF = 3.0e38f;
 
-template <bool SELF>
+template <bool SELF, bool TIES>
 __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeom g)
 {
     __shared__ float lx[4][kCap + 1], ly[4][kCap + 1], lz[4][kCap + 1];
@@ -546,6 +548,39 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
                 d64 = gdist64(qx, qy, qz, r.x, r.y, r.z);
                 wrow = rec_row(r);
                 settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
+            } else if (TIES && bestpos != 0xffffffffu && J.slack32 == 0.0 && T <= (uint32_t)kCap) {
+                // Near or exact tie (the rule on voxelised content).  Both clouds are fp32-exact, so the
+                // staged fp32 coordinates ARE the fp64 coordinates: settle the tie right here with the
+                // reference's fp64 arithmetic over the candidates within the band, smallest row first.
+                float tf = (float)thr;
+                tf = __uint_as_float(__float_as_uint(tf) + 1u);
+                Best b;
+                b.d = INFINITY;
+                b.idx = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    for (uint32_t f = rs[k]; f < rs[k] + rl[k]; ++f) {
+                        const float x = lx[w][f], y = ly[w][f], z = lz[w][f];
+                        const float ax = fx - x, ay = fy - y, az = fz - z;
+                        float d = ax * ax;
+                        d = __builtin_fmaf(ay, ay, d);
+                        d = __builtin_fmaf(az, az, d);
+                        if (d <= tf) {
+                            // rows are not staged for plain directions: fetch the few that matter
+                            const int row = SELF ? lrow[w][f] : srecs[f + (S[k] - off[k])].idx;
+                            if (SELF && row == qrow) continue;
+                            const double e = gdist64(qx, qy, qz, (double)x, (double)y, (double)z);
+                            const bool better = e < b.d || (e == b.d && row < b.idx);
+                            b.d = better ? e : b.d;
+                            b.idx = better ? row : b.idx;
+                        }
+                    }
+                }
+                if (b.idx != 0x7fffffff) {
+                    d64 = b.d;
+                    wrow = b.idx;
+                    settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
+                }
             }
             if (settled) {
                 J.idx_out[qrow - J.row_base] = wrow;
@@ -646,7 +681,7 @@ static bool use_coop()
 // One geometry for BOTH clouds (union bounding box, cell edge from the mean point count): a query's
 // cell in the searched cloud's grid is then the cell it was sorted into in its own cloud's grid, which is
 // what lets the cooperative kernel work on runs of consecutive cells.
-static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells)
+static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells, double h_scale)
 {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     double npts = 0.0;
@@ -670,8 +705,8 @@ static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells)
         if (ext[a] > 0.0) { vol *= ext[a]; ++nz; }
     }
     double h = 1.0;
-    if (nz > 0) h = pow(vol * points_per_cell() / npts, 1.0 / nz);
-    const int64_t cap = 1ll << 27;
+    if (nz > 0) h = pow(vol * points_per_cell() / npts, 1.0 / nz) * h_scale;
+    const int64_t cap = 1ll << 26;
     for (int pass = 0; pass < 64; ++pass) {
         ncells = 1;
         for (int a = 0; a < 3; ++a) {
@@ -706,16 +741,83 @@ static GridGeom geom_of(const Grid &gr)
     return g;
 }
 
+// occupied cells of a histogram
+__global__ __launch_bounds__(256) void k_count_occupied(const uint32_t *__restrict__ hist, int64_t m, unsigned long long *__restrict__ out)
+{
+    unsigned int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) c += hist[i] ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+// Cell edge for this pair of clouds.  The volume rule (ppc points per cell of the bounding box) is
+// right for space-filling data; point clouds of surfaces (all real PCC content) leave most cells empty
+// and pile dozens of points into the occupied ones, which multiplies the candidates per query.  So the
+// edge is shrunk until the OCCUPIED cells of the larger cloud hold ~2 ppc points on average (or the cell
+// budget is reached).  Costs a few histogram passes and host round trips, once per pair of clouds:
+// the result is cached and survives pccm_drop_caches().
+static int decide_scale(pccm_ctx *ctx, uint64_t key)
+{
+    Grid &gr = ctx->grid;
+    if (gr.scale_key == key) return PCCM_OK;
+    if (ctx->capturing) {
+        ctx->capture_failed = true;
+        return fail(PCCM_E_STATE, "the grid geometry must be decided before graph capture: run pccm_nn once first");
+    }
+    const int big = ctx->cloud[1].n > ctx->cloud[0].n ? 1 : 0;
+    const Cloud &c = ctx->cloud[big];
+    double scale = 1.0;
+    const double target = 2.0 * points_per_cell();
+    for (int it = 0; it < 4 && c.n > 0; ++it) {
+        GridGeom g;
+        int64_t ncells;
+        choose_geometry(ctx, g, ncells, scale);
+        int rc;
+        if ((rc = ensure(ctx, ctx->g_hist, (size_t)(ncells + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)c.n * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, ctx->g_rank, (size_t)c.n * sizeof(uint32_t)))) return rc;
+        uint32_t *hist = (uint32_t *)ctx->g_hist.p;
+        unsigned long long *counter = (unsigned long long *)ctx->stats.p;
+        PCCM_HIP(hipMemsetAsync(hist, 0, (size_t)(ncells + 1) * sizeof(uint32_t), ctx->stream));
+        PCCM_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+        BuildJobs bj;
+        bj.njobs = 1;
+        bj.j[0] = {c.xyz64, 0, c.n, hist};
+        bj.j[1] = bj.j[0];
+        bj.total = c.n;
+        hipLaunchKernelGGL(k_grid_cells, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream, bj, g,
+                           (uint32_t *)ctx->g_cell_of.p, (uint32_t *)ctx->g_rank.p);
+        hipLaunchKernelGGL(k_count_occupied, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)hist, ncells, counter);
+        unsigned long long occ = 0;
+        PCCM_HIP(hipMemcpyAsync(&occ, counter, sizeof(occ), hipMemcpyDeviceToHost, ctx->stream));
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+        const double mean = (double)c.n / (double)(occ ? occ : 1);
+        if (mean <= 1.5 * target) break;
+        GridGeom g2;
+        int64_t nc2;
+        const double next = scale * fmax(0.35, pow(target / mean, 1.0 / 2.4));
+        choose_geometry(ctx, g2, nc2, next);
+        if (nc2 == ncells) break;                  // cell budget or per-axis limit reached
+        scale = next;
+    }
+    gr.scale = scale;
+    gr.scale_key = key;
+    return PCCM_OK;
+}
+
 // (re)build the combined grid when either cloud changed or the caches were dropped
 static int ensure_grid(pccm_ctx *ctx)
 {
     Grid &gr = ctx->grid;
     const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
     if (gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p) return PCCM_OK;
+    int rc0 = decide_scale(ctx, key);
+    if (rc0) return rc0;
     ProfScope ps(ctx, PCCM_K_GRID_BUILD);
     GridGeom g;
     int64_t ncells;
-    choose_geometry(ctx, g, ncells);
+    choose_geometry(ctx, g, ncells, gr.scale);
     const int64_t n0 = ctx->cloud[0].n, n1 = ctx->cloud[1].n;
     int rc;
     if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
@@ -814,12 +916,15 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         if (use_coop()) {
             dim3 grid((unsigned)((chunks + 3) / 4));
             dim3 wgrid((unsigned)(nqmax < 4096 ? (nqmax + 3) / 4 : 1024));
+            const bool ties = ctx->cloud[0].all_int && ctx->cloud[1].all_int;
             if (self) {
-                hipLaunchKernelGGL((k_grid_query_coop<true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                if (ties) hipLaunchKernelGGL((k_grid_query_coop<true, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                else hipLaunchKernelGGL((k_grid_query_coop<true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 hipLaunchKernelGGL((k_grid_tail_wave<true>), wgrid, dim3(256), 0, ctx->stream, jobs, g);
                 hipLaunchKernelGGL((k_grid_query<true>), tgrid, dim3(256), 0, ctx->stream, jobs, g, 1);
             } else {
-                hipLaunchKernelGGL((k_grid_query_coop<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                if (ties) hipLaunchKernelGGL((k_grid_query_coop<false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                else hipLaunchKernelGGL((k_grid_query_coop<false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 hipLaunchKernelGGL((k_grid_tail_wave<false>), wgrid, dim3(256), 0, ctx->stream, jobs, g);
                 hipLaunchKernelGGL((k_grid_query<false>), tgrid, dim3(256), 0, ctx->stream, jobs, g, 1);
             }

@@ -30,6 +30,7 @@ struct Cloud {
     double *nrm64 = nullptr;    // [n_nrm][3]
     int64_t n_nrm = 0;
     bool exact32 = true;        // every coordinate survives the fp64 -> fp32 -> fp64 round trip
+    bool all_int = false;       // ... and is an integer (voxelised content: exact ties are the rule)
     double maxabs = 0.0;
     double bb_min[3] = {0, 0, 0}, bb_max[3] = {0, 0, 0};   // bounding box (fp64 coordinates)
     uint64_t version = 0;       // bumped by pccm_set_cloud (grid caches key on it)
@@ -60,6 +61,8 @@ struct GridRec {          // 32 B: fp64 position + original row
 
 struct Grid {                    // one geometry, both clouds (grid engine)
     uint64_t key = 0;              // derived from both Cloud::version values (0 = none)
+    uint64_t scale_key = 0;        // clouds the cell-edge scale below was decided for
+    double scale = 1.0;            // shrink factor of the volume-rule cell edge (occupancy-adaptive)
     int dim[3] = {1, 1, 1};
     double org[3] = {0, 0, 0};
     double h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};   // cell edge per axis

@@ -7,7 +7,8 @@ namespace pccm {
 // Ingest: packed [n][3] f32/f64 rows -> float4 scan copy (padded) + fp64 copy, and three
 // statistics: [0] max |coordinate| (as fp64 bits; non-negative doubles order like uint64), [1] number
 // of coordinates that do not survive fp64 -> fp32 -> fp64, [2] number of non-finite coordinates,
-// [3..5] / [6..8] order keys of the bounding box minimum / maximum per axis (for the grid engine).
+// [3..5] / [6..8] order keys of the bounding box minimum / maximum per axis (for the grid engine),
+// [9] number of coordinates that are not integers (voxelised content has none).
 // ------------------------------------------------------------------------------------------
 // monotonic map double -> uint64 (so that atomicMin/atomicMax order like the doubles do)
 __device__ __forceinline__ unsigned long long order_key(double v)
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long mx = 0;
     unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};   // bounding box keys
-    int inexact = 0, bad = 0;
+    int inexact = 0, bad = 0, frac = 0;
     if (i < n) {
         double v[3];
         float f[3];
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
             v[a] = (double)src[3 * i + a];
             f[a] = (float)v[a];
             inexact += ((double)f[a] != v[a]) ? 1 : 0;
+            frac += (floor(v[a]) != v[a]) ? 1 : 0;
             bad += isfinite(v[a]) ? 0 : 1;
             unsigned long long b = (unsigned long long)__double_as_longlong(fabs(v[a]));
             mx = b > mx ? b : mx;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
         mx = o > mx ? o : mx;
         inexact += __shfl_xor(inexact, off);
         bad += __shfl_xor(bad, off);
+        frac += __shfl_xor(frac, off);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             unsigned long long l = __shfl_xor(lo[a], off), h = __shfl_xor(hi[a], off);
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
         if (mx) atomicMax(&stats[0], mx);
         if (inexact) atomicAdd(&stats[1], (unsigned long long)inexact);
         if (bad) atomicAdd(&stats[2], (unsigned long long)bad);
+        if (frac) atomicAdd(&stats[9], (unsigned long long)frac);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             atomicMin(&stats[3 + a], lo[a]);

@@ -34,6 +34,14 @@ def clouds(kind, na, nb, seed):
         a = rng.random((na, 3), dtype=np.float32)
         a[na // 2:] = a[: na - na // 2]
         return a, a[rng.permutation(na)[:nb]].copy()
+    if kind == "surface":       # voxelised closed surface (the shape of MPEG 8i content): integer coordinates, exact ties
+        u = rng.random(na * 2) * 2 * np.pi
+        v = np.arccos(2 * rng.random(na * 2) - 1)
+        r = 180 + 20 * np.sin(3 * u) * np.sin(5 * v)
+        p = np.stack([256 + r * np.sin(v) * np.cos(u), 256 + 0.6 * r * np.sin(v) * np.sin(u), 256 + r * np.cos(v)], 1)
+        a = np.unique(np.round(p).astype(np.float32), axis=0)[:na]
+        b = np.unique(np.round(a + rng.normal(0, 0.7, a.shape)).astype(np.float32), axis=0)[:nb]
+        return a, b
     if kind == "far":
         return (rng.random((na, 3)) * 1e6 + 1e9), (rng.random((nb, 3)) * 1e6 + 1e9)
     raise ValueError(kind)
@@ -53,7 +61,8 @@ def engine():
 
 CASES = [("uniform32", 5, 7), ("uniform32", 1, 1), ("uniform32", 2, 1), ("uniform32", 1000, 1000),
          ("uniform32", 1023, 1025), ("uniform32", 4097, 2049), ("f64", 3000, 2500), ("lattice", 2000, 2000),
-         ("voxel10", 5000, 4000), ("dup", 600, 500), ("far", 800, 900), ("uniform32", 70000, 65537)]
+         ("voxel10", 5000, 4000), ("dup", 600, 500), ("far", 800, 900), ("uniform32", 70000, 65537),
+         ("surface", 60000, 60000)]
 
 
 @pytest.mark.parametrize("engine_name", ENGINES)
