@@ -150,6 +150,10 @@ int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum);
 /* Unsharded shortcut (world = 1): out = {np.sum, np.min, np.max} of the whole column in one call. */
 int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, double out[3]);
 
+/* Host-only helper (no GPU): rows of RGB in [n][3] -> the target scheme of transform_colors(),
+ * metric.py:261-290 (scheme 1 = "ycc", 2 = "yuv"), bit-compatible with the reference's per-row np.matmul. */
+int pccm_color_transform(const double *rgb, int64_t n, int scheme, double *out);
+
 /* Forget the search structures derived from the clouds (the grid engine's cell-sorted copies,
  * the analogue of the KD-trees CloudPair.__init__ builds at cloud_pair.py:65), so that the next
  * pccm_nn() rebuilds them.  bench.py calls it every step: a step pays for its builds. */

@@ -30,7 +30,7 @@ SYMBOLS = (
     "pccm_set_cloud", "pccm_set_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
-    "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
+    "pccm_color_transform", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
 )
@@ -84,6 +84,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_reduce_total.argtypes = [vp, i32, i32, i32, dp]
     lib.pccm_sync.argtypes = [vp]
     lib.pccm_drop_caches.argtypes = [vp]
+    lib.pccm_color_transform.argtypes = [vp, i64, i32, vp]
     lib.pccm_graph_begin.argtypes = [vp]
     lib.pccm_graph_end.argtypes = [vp, ctypes.POINTER(i32)]
     lib.pccm_graph_launch.argtypes = [vp, i32]
@@ -131,6 +132,17 @@ def finish_sum(xvec: np.ndarray, n: int) -> float:
     out = ctypes.c_double(0.0)
     _check(load().pccm_finish_sum(xvec.ctypes.data_as(ctypes.c_void_p), int(n), ctypes.byref(out)))
     return np.float64(out.value)
+
+
+def color_transform(colors: np.ndarray, scheme: str) -> np.ndarray:
+    """rgb rows -> "ycc" / "yuv" rows (host helper of libpccm; see pccm_color_transform)."""
+    src = np.ascontiguousarray(colors, dtype=np.float64)
+    if src.ndim != 2 or src.shape[1] != 3:
+        raise ValueError("colors must have shape (N, 3)")
+    out = np.empty_like(src)
+    _check(load().pccm_color_transform(src.ctypes.data_as(ctypes.c_void_p), src.shape[0], {"ycc": 1, "yuv": 2}[scheme],
+                                       out.ctypes.data_as(ctypes.c_void_p)))
+    return out
 
 
 def _as_rows(a, what: str) -> Tuple[object, int, int, int, object]:

@@ -790,6 +790,24 @@ int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
     return PCCM_OK;
 }
 
+// Host helper for the colour metrics (metric.py:261-290): out[r] = M * rgb[r] for the BT.709 "ycc" (1) or
+// the "yuv" (2) matrix.  The reference maps every row with np.matmul(M, c); on the authoring host
+// (NumPy 2.2.6 / OpenBLAS dgemv) that evaluates each component as fma(m2*c2, fma(m0*c0, m1*c1)) -- pinned
+// by tests/golden/*color* -- and that is the order used here.
+int pccm_color_transform(const double *rgb, int64_t n, int scheme, double *out)
+{
+    static const double kYcc[9] = {0.2126, 0.7152, 0.0722, -0.1146, -0.3854, 0.5, 0.5, -0.4542, -0.0458};
+    static const double kYuv[9] = {0.25, 0.5, 0.25, 1, 0, -1, -0.5, 1, -0.5};
+    if (!rgb || !out || n < 0) return fail(PCCM_E_ARG, "bad argument");
+    const double *m = scheme == 1 ? kYcc : (scheme == 2 ? kYuv : nullptr);
+    if (!m) return fail(PCCM_E_ARG, "unknown colour scheme %d", scheme);
+    for (int64_t r = 0; r < n; ++r) {
+        const double c0 = rgb[3 * r], c1 = rgb[3 * r + 1], c2 = rgb[3 * r + 2];
+        for (int i = 0; i < 3; ++i) out[3 * r + i] = fma(m[3 * i + 2], c2, fma(m[3 * i], c0, m[3 * i + 1] * c1));
+    }
+    return PCCM_OK;
+}
+
 int pccm_drop_caches(pccm_ctx *ctx)
 {
     CHECK_CTX(ctx);

@@ -245,9 +245,13 @@ def transform_colors(colors: np.ndarray, source_scheme: str, target_scheme: str)
     """metric.py:261-290: rows are mapped by the 3x3 matrix of the target scheme."""
     if source_scheme == target_scheme:
         return colors
-    matrix = _FROM_RGB[target_scheme] if source_scheme == "rgb" else None
+    if source_scheme != "rgb" or target_scheme not in _FROM_RGB:
+        raise TypeError(f"no transform from {source_scheme!r} to {target_scheme!r}")   # the reference fails here too
     colors = np.asarray(colors)
-    return np.stack([np.matmul(matrix, row) for row in colors]) if len(colors) else colors
+    if not len(colors):
+        return colors
+    from . import _native
+    return _native.color_transform(colors, target_scheme)      # == np.matmul(matrix, row) for every row, in C
 
 
 def get_color_peak(color_scheme: str) -> np.float64:

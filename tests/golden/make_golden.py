@@ -108,6 +108,12 @@ def cases():
     b = a + 1e-1 * np.linspace(1.0, 3, 3)
     nz = np.tile(np.array([[0.0, 0.0, 1.0]]), (3, 1))
     out["fixture_eye3"] = dict(a=a, b=b, na=nz, nb=nz, extent=[1.5, 1.0, 0.5])
+    # the same fixture with its colours (tests/unit/test_metric.py:16,19,23,25: colours = points)
+    out["fixture_eye3_color"] = dict(a=a, b=b, na=nz, nb=nz, extent=[1.5, 1.0, 0.5], ca=a.copy(), cb=b.copy())
+    rc = np.random.default_rng(77)
+    out["uniform_300_color"] = dict(a=_uniform(300, 41), b=_uniform(300, 42), na=_normals(300, 43), nb=_normals(300, 44),
+                                    extent=[1.0, 0.9, 0.8], ca=np.round(rc.random((300, 3)) * 255) / 255.0,
+                                    cb=np.round(rc.random((300, 3)) * 255) / 255.0)
     # (2) seeded uniform fp32 clouds of equal size (BASELINE.json configs, scaled down)
     for n in (1, 2, 3, 64, 257, 1000):
         out[f"uniform_{n}"] = dict(a=_uniform(n, 1234 + n), b=_uniform(n, 5678 + n),
@@ -135,10 +141,12 @@ def cases():
     return out
 
 
-def _cloud(pts, nrm, extent):
+def _cloud(pts, nrm, extent, colors=None):
     c = PointCloud()
     c.points = np.array(pts, dtype=np.float64)
     c.normals = np.array(nrm, dtype=np.float64)
+    if colors is not None:
+        c.colors = np.array(colors, dtype=np.float64)
     c._extent = extent
     return c
 
@@ -150,7 +158,8 @@ def run_case(name, spec):
     from open_pcc_metric.options import CalculateOptions, transform_options
 
     rec = {k: np.asarray(v, dtype=np.float64) for k, v in spec.items()}
-    pair = CloudPair(_cloud(spec["a"], spec["na"], spec["extent"]), _cloud(spec["b"], spec["nb"], spec["extent"]))
+    pair = CloudPair(_cloud(spec["a"], spec["na"], spec["extent"], spec.get("ca")),
+                     _cloud(spec["b"], spec["nb"], spec["extent"], spec.get("cb")))
     rec["left_d2"] = np.asarray(pair.get_left_neighbour_distances())
     rec["right_d2"] = np.asarray(pair.get_right_neighbour_distances())
     rec["left_err"] = np.asarray(pair.get_left_error_vector())
@@ -174,6 +183,17 @@ def run_case(name, spec):
             results[tag] = [[list(k), float(v)] for k, v in d.items()]
             df = res.as_df()
             texts[tag] = {"string": df.to_string(), "csv": df.to_csv()}
+    if "ca" in spec:            # colour rows (options.py:58-82), transform_colors / ColorMSE / ColorPSNR
+        for scheme in ("rgb", "ycc"):
+            MetricCalculator._calculated_metrics.clear()
+            opts = CalculateOptions(color=scheme, hausdorff=False, point_to_plane=False)
+            res = MetricCalculator(pair).calculate(transform_options(opts))
+            rows = []
+            for k, v in res.as_dict().items():
+                rows.append([list(k), [float(x) for x in np.atleast_1d(v)]])
+            results["c" + scheme] = rows
+            df = res.as_df()
+            texts["c" + scheme] = {"string": df.to_string(), "csv": df.to_csv()}
     # per-point D2 vectors, each direction on its own (one may raise, quirk Q1)
     for is_left in (True, False):
         side = "left" if is_left else "right"

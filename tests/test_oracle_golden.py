@@ -34,6 +34,8 @@ def test_report_scalars_match_reference(golden):
     peak = float(np.max(golden["extent"]))
     assert golden["meta"]["results"], "no result rows in the golden file"
     for tag, rows in golden["meta"]["results"].items():
+        if tag.startswith("c"):
+            continue                                  # colour rows: tests/test_io_color.py
         rep = p.report(hausdorff=tag[1] == "1", point_to_plane_=tag[3] == "1", peak=peak)
         assert [tuple(k) for k, _ in rows] == list(rep.keys())      # options.py row order
         for key, val in rows:
