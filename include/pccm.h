@@ -98,6 +98,14 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
  * for PCCM_NORMAL_NEIGHBOUR; PCCM_NORMAL_ROW only needs the rows it indexes. */
 int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype, int on_device);
 
+/* Replaces clouds[k].estimate_normals(), cloud_pair.py:61-64 (Open3D EstimateNormals, default
+ * KDTreeSearchParamKNN(knn = 30)): per point, the eigenvector of the smallest eigenvalue of the
+ * covariance of its knn nearest points of the same cloud (itself included).  Open3D's own arithmetic
+ * and sign convention cannot be pinned without it; here the component of largest
+ * magnitude is positive.  The normals stay on the device; pccm_get_normals copies [n][3] doubles out. */
+int pccm_estimate_normals(pccm_ctx *ctx, int which, int knn);
+int pccm_get_normals(pccm_ctx *ctx, int which, double *out);
+
 /* Query-axis shard of this context: rank r of `world` owns, in every direction, the rows
  * [begin, end) of the iterating cloud returned by pccm_shard_range (boundaries are multiples
  * of 128 rows so that reduction leaves never straddle ranks).  Default: rank 0 of 1. */

@@ -27,7 +27,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy",
-    "pccm_set_cloud", "pccm_set_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
+    "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
     "pccm_color_transform", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
@@ -68,6 +68,8 @@ def load() -> ctypes.CDLL:
     lib.pccm_set_cloud.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_set_normals.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_set_shard.argtypes = [vp, i32, i32]
+    lib.pccm_estimate_normals.argtypes = [vp, i32, i32]
+    lib.pccm_get_normals.argtypes = [vp, i32, vp]
     lib.pccm_shard_range.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.pccm_nn.argtypes = [vp, i32, i32]
     lib.pccm_nn_pair.argtypes = [vp, i32]
@@ -199,6 +201,15 @@ class Engine:
     def set_normals(self, which: int, normals) -> None:
         ptr, n, dt, dev, keep = _as_rows(normals, "normals")
         _check(self._lib.pccm_set_normals(self._ctx, int(which), ptr, n, dt, dev))
+
+    def estimate_normals(self, which: int, knn: int = 30) -> None:
+        """Open3D-style normals (k-NN covariance, smallest eigenvector) computed and kept on the device."""
+        _check(self._lib.pccm_estimate_normals(self._ctx, int(which), int(knn)))
+
+    def get_normals(self, which: int) -> np.ndarray:
+        out = np.empty((self._n[which], 3), dtype=np.float64)
+        _check(self._lib.pccm_get_normals(self._ctx, int(which), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     def set_shard(self, rank: int, world: int) -> None:
         _check(self._lib.pccm_set_shard(self._ctx, int(rank), int(world)))

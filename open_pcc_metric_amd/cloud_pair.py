@@ -11,9 +11,10 @@ array to the host unless a caller asks for one.
 
 Differences from the reference, all deliberate:
 
-* inputs are never mutated and normals are never estimated (quirk Q5; normal estimation is
-  Open3D code): point-to-plane metrics need normals on both clouds
-  and raise ``ValueError`` otherwise;
+* inputs are never mutated (quirk Q5).  A cloud without normals gets them estimated on the GPU the
+  first time a point-to-plane metric needs them (k = 30 nearest-neighbour covariance, as Open3D's
+  ``estimate_normals`` at cloud_pair.py:61-64 does; not bit-pinned, see csrc/pccm_normals.hip) and
+  kept inside the pair; ``estimate_normals=False`` raises ``ValueError`` instead;
 * ``normal_index="row"`` (default) reproduces the reference's D2, including its ``IndexError``
   when the iterating cloud is larger than the other one (quirk Q1); ``"neighbour"`` uses the
   matched point's normal;
@@ -184,7 +185,7 @@ class CloudPair:
 
     def __init__(self, origin_cloud, reconst_cloud, *, device: typing.Optional[int] = None,
                  nn_engine: str = "auto", normal_index: str = "row", extent=None, group=None,
-                 use_graph: bool = False, _engine=None):
+                 use_graph: bool = False, estimate_normals: bool = True, normals_knn: int = 30, _engine=None):
         if normal_index not in nat.NORMAL_MODES:
             raise ValueError("normal_index must be 'row' or 'neighbour'")
         if nn_engine not in nat.ENGINES:
@@ -193,6 +194,8 @@ class CloudPair:
         self.normal_index = normal_index
         self.nn_engine = nn_engine
         self._use_graph = bool(use_graph)
+        self._estimate_normals, self._normals_knn = bool(estimate_normals), int(normals_knn)
+        self._estimated = [False, False]
         self._xchg, self._xchg_wanted = {}, []
         self._graph_id = None
         self._last_wanted = None
@@ -292,11 +295,19 @@ class CloudPair:
             self._idx_cache[direction] = self._gather(direction, idx).astype(np.int64)
         return self._idx_cache[direction]
 
+    def _normals_ready(self, which: int) -> bool:
+        return self._estimated[which] or _has_normals(self.clouds[which])
+
     def _require_normals(self, which: int) -> None:
-        if not _has_normals(self.clouds[which]):
+        if self._normals_ready(which):
+            return
+        if not (self._estimate_normals and hasattr(self._engine, "estimate_normals")):
             raise ValueError(
-                f"cloud {which} has no normals: point-to-plane metrics need precomputed normals "
+                f"cloud {which} has no normals: point-to-plane metrics need them "
                 "(the reference would call Open3D's estimate_normals here, cloud_pair.py:61-64)")
+        self._engine.estimate_normals(which, self._normals_knn)      # stays in HBM; inputs are not touched
+        self._estimated[which] = True
+        self._graph_id = None                                        # device buffers changed
 
     # -- reference surface, cloud_pair.py:82-124 -------------------------------------------------
     @property
@@ -333,7 +344,11 @@ class CloudPair:
     def get_normals(self, which: int):
         """np.asarray(clouds[which].normals), tagged for the fused projection (metric.py:92-98)."""
         self._require_normals(which)
-        view = np.asarray(_host_rows(self.clouds[which].normals)).view(CloudNormalsView)
+        if self._estimated[which]:
+            host = self._engine.get_normals(which)
+        else:
+            host = np.asarray(_host_rows(self.clouds[which].normals))
+        view = host.view(CloudNormalsView)
         view._pccm_origin = (id(self), which)
         return view
 
@@ -376,8 +391,14 @@ class CloudPair:
             direction = nat.DIR_LEFT if is_left else nat.DIR_RIGHT
             if not p2p:
                 requests.append((direction, nat.METRIC_D1))
-            elif _has_normals(self.clouds[1 if is_left else 0]):
-                n_other = len(self.clouds[1 if is_left else 0].normals)
+            else:
+                other = 1 if is_left else 0
+                try:
+                    self._require_normals(other)
+                except ValueError:
+                    continue          # surfaces when the column is evaluated
+                n_other = self._engine.n_iter(nat.DIR_RIGHT if other else nat.DIR_LEFT) if self._estimated[other] \
+                    else len(self.clouds[other].normals)
                 if self.normal_index == "row" and eng.shard_range(direction)[1] > n_other:
                     continue      # row-indexed normals out of range: surfaces where the reference raises
                 requests.append((direction, nat.METRIC_D2))

@@ -345,6 +345,27 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
     return PCCM_OK;
 }
 
+int pccm_estimate_normals(pccm_ctx *ctx, int which, int knn)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
+    return estimate_normals(ctx, which, knn);
+}
+
+int pccm_get_normals(pccm_ctx *ctx, int which, double *out)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
+    if (!out) return fail(PCCM_E_ARG, "null pointer");
+    const Cloud &c = ctx->cloud[which];
+    if (!c.nrm64 || c.n_nrm <= 0) return fail(PCCM_E_STATE, "cloud %d has no normals", which);
+    PCCM_HIP(hipMemcpyAsync(out, c.nrm64, (size_t)c.n_nrm * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    return PCCM_OK;
+}
+
 int pccm_set_shard(pccm_ctx *ctx, int rank, int world)
 {
     CHECK_CTX(ctx);

@@ -958,4 +958,6 @@ void grid_release(pccm_ctx *ctx)
 
 void grid_invalidate(pccm_ctx *ctx) { ctx->grid.key = 0; }
 
+int grid_ensure(pccm_ctx *ctx) { return ensure_grid(ctx); }
+
 }  // namespace pccm

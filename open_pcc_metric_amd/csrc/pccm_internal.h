@@ -165,6 +165,8 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
 int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs);
 void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
+int grid_ensure(pccm_ctx *ctx);
+int estimate_normals(pccm_ctx *ctx, int which, int k);
 int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
 
 struct PointJob {               // one D2 / PROJ column (k_point_jobs)

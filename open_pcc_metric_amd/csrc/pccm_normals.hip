@@ -1,0 +1,272 @@
+// Normal estimation on the GPU.
+//
+// Stands under `clouds[k].estimate_normals()` in CloudPair.__init__, open_pcc_metric/cloud_pair.py:61-64,
+// i.e. Open3D 0.18 PointCloud::EstimateNormals with its defaults (KDTreeSearchParamKNN(knn = 30),
+// fast_normal_computation): for every point, the covariance of its 30 nearest points of the same cloud
+// (the point itself included) and the eigenvector of the smallest eigenvalue.  Open3D is not in the
+// reference checkout, so this is a restatement of the published algorithm and is NOT parity-pinned:
+//   - neighbours: exact k-NN, squared distance in fp64 ((dx*dx)+(dy*dy))+(dz*dz), ties to the smaller row;
+//   - covariance: E[d d^T] - E[d] E[d]^T with d = p - q (Open3D forms the same matrix from raw moments;
+//     shifting by the query point only improves the conditioning);
+//   - eigenvector: closed-form eigenvalues of the symmetric 3x3 (trigonometric form on the scaled matrix)
+//     and the largest cross product of two rows of (C - lambda I), as in Open3D's FastEigen3x3;
+//   - fewer than 3 points in the cloud, or a degenerate covariance: (0, 0, 1) (Open3D's default normal);
+//   - sign: Open3D leaves it to the eigen-solver; here the component of largest magnitude is made positive.
+//     D2 squares the projection (metric.py:179), so no metric depends on the sign.
+// The neighbours come from the grid engine's cell-sorted records: one thread per point scans the cube
+// [c-r, c+r]^3 ring by ring, keeping the k best (d2, row) in a sorted private list, until the k-th best is
+// provably closer than anything outside the cube (same stop rule as the 1-NN search).  Points that are
+// still open after kKnnMaxRing rings (isolated outliers) are finished by an exact block-per-point scan of
+// the whole cloud.
+#include "pccm_internal.h"
+
+namespace pccm {
+
+constexpr int kKnnMax = 64;        // largest supported k
+constexpr int kKnnMaxRing = 6;
+
+struct KnnGeom {
+    int dim[3];
+    double org[3], h[3], inv_h[3], slack[3];
+};
+
+__device__ __forceinline__ int ncell_coord(double v, double org, double inv_h, int dim)
+{
+    double t = floor(__dmul_rn(__dsub_rn(v, org), inv_h));
+    t = t < 0.0 ? 0.0 : t;
+    const double top = (double)(dim - 1);
+    t = t > top ? top : t;
+    return (int)t;
+}
+
+__device__ __forceinline__ double nd2(double qx, double qy, double qz, double rx, double ry, double rz)
+{
+    double dx = __dsub_rn(qx, rx), dy = __dsub_rn(qy, ry), dz = __dsub_rn(qz, rz);
+    double d = __dmul_rn(dx, dx);
+    d = __dadd_rn(d, __dmul_rn(dy, dy));
+    d = __dadd_rn(d, __dmul_rn(dz, dz));
+    return d;
+}
+
+// sorted insertion of (d, row) into the k best kept in ascending (d, row) order
+__device__ __forceinline__ void knn_insert(double *bd, int *bi, int k, int &cnt, double d, int row)
+{
+    if (cnt == k && !(d < bd[k - 1] || (d == bd[k - 1] && row < bi[k - 1]))) return;
+    int p = cnt < k ? cnt : k - 1;
+    while (p > 0 && (d < bd[p - 1] || (d == bd[p - 1] && row < bi[p - 1]))) {
+        bd[p] = bd[p - 1];
+        bi[p] = bi[p - 1];
+        --p;
+    }
+    bd[p] = d;
+    bi[p] = row;
+    if (cnt < k) ++cnt;
+}
+
+// eigenvector of the smallest eigenvalue of the symmetric matrix [a00 a01 a02; a01 a11 a12; a02 a12 a22]
+__device__ void smallest_eigenvector(double a00, double a01, double a02, double a11, double a12, double a22, double n[3])
+{
+    n[0] = 0.0; n[1] = 0.0; n[2] = 1.0;
+    double mx = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fmax(fabs(a01), fmax(fabs(a02), fabs(a12)))));
+    if (!(mx > 0.0)) return;
+    const double s = 1.0 / mx;
+    a00 *= s; a01 *= s; a02 *= s; a11 *= s; a12 *= s; a22 *= s;
+    const double norm = a01 * a01 + a02 * a02 + a12 * a12;
+    double lam;
+    if (norm > 0.0) {
+        const double q = (a00 + a11 + a22) / 3.0;
+        const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+        const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * norm) / 6.0);
+        const double c00 = b11 * b22 - a12 * a12, c01 = a01 * b22 - a12 * a02, c02 = a01 * a12 - b11 * a02;
+        const double det = (b00 * c00 - a01 * c01 + a02 * c02) / (p * p * p);
+        const double half = fmin(fmax(0.5 * det, -1.0), 1.0);
+        const double angle = acos(half) / 3.0;
+        lam = q + 2.0 * p * cos(angle + 2.0943951023931953);      // smallest root: + 2*pi/3
+    } else {
+        lam = fmin(a00, fmin(a11, a22));
+    }
+    // rows of (A - lam I); the eigenvector is orthogonal to all of them: take the best-conditioned cross product
+    const double r0[3] = {a00 - lam, a01, a02}, r1[3] = {a01, a11 - lam, a12}, r2[3] = {a02, a12, a22 - lam};
+    double c[3][3];
+    c[0][0] = r0[1] * r1[2] - r0[2] * r1[1]; c[0][1] = r0[2] * r1[0] - r0[0] * r1[2]; c[0][2] = r0[0] * r1[1] - r0[1] * r1[0];
+    c[1][0] = r0[1] * r2[2] - r0[2] * r2[1]; c[1][1] = r0[2] * r2[0] - r0[0] * r2[2]; c[1][2] = r0[0] * r2[1] - r0[1] * r2[0];
+    c[2][0] = r1[1] * r2[2] - r1[2] * r2[1]; c[2][1] = r1[2] * r2[0] - r1[0] * r2[2]; c[2][2] = r1[0] * r2[1] - r1[1] * r2[0];
+    int best = 0;
+    double bl = -1.0;
+    for (int k = 0; k < 3; ++k) {
+        const double l = c[k][0] * c[k][0] + c[k][1] * c[k][1] + c[k][2] * c[k][2];
+        if (l > bl) { bl = l; best = k; }
+    }
+    if (!(bl > 1.0e-280)) return;                           // (numerically) isotropic or rank-0 spread
+    const double inv = 1.0 / sqrt(bl);
+    double v0 = c[best][0] * inv, v1 = c[best][1] * inv, v2 = c[best][2] * inv;
+    const double m0 = fabs(v0), m1 = fabs(v1), m2 = fabs(v2);
+    const double lead = (m0 >= m1 && m0 >= m2) ? v0 : (m1 >= m2 ? v1 : v2);
+    if (lead < 0.0) { v0 = -v0; v1 = -v1; v2 = -v2; }
+    n[0] = v0; n[1] = v1; n[2] = v2;
+}
+
+__device__ void normal_from_neighbours(const double *__restrict__ x64, double qx, double qy, double qz, const int *bi, int cnt,
+                                       double *__restrict__ out)
+{
+    double n[3] = {0.0, 0.0, 1.0};
+    if (cnt >= 3) {
+        double m0 = 0, m1 = 0, m2 = 0, s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const double *p = x64 + 3 * (int64_t)bi[k];
+            const double dx = p[0] - qx, dy = p[1] - qy, dz = p[2] - qz;
+            m0 += dx; m1 += dy; m2 += dz;
+            s00 += dx * dx; s01 += dx * dy; s02 += dx * dz; s11 += dy * dy; s12 += dy * dz; s22 += dz * dz;
+        }
+        const double inv = 1.0 / (double)cnt;
+        m0 *= inv; m1 *= inv; m2 *= inv;
+        smallest_eigenvector(s00 * inv - m0 * m0, s01 * inv - m0 * m1, s02 * inv - m0 * m2, s11 * inv - m1 * m1,
+                             s12 * inv - m1 * m2, s22 * inv - m2 * m2, n);
+    }
+    out[0] = n[0]; out[1] = n[1]; out[2] = n[2];
+}
+
+// one thread per point (in cell-sorted order); rings 0..kKnnMaxRing
+__global__ __launch_bounds__(256) void k_knn_normals(const GridRec *__restrict__ recs, int64_t qbase, int64_t n, KnnGeom g,
+                                                     const uint32_t *__restrict__ cell_start, const double *__restrict__ x64,
+                                                     int k, double *__restrict__ nrm_out, int32_t *__restrict__ open_list,
+                                                     uint32_t *__restrict__ open_count)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const double4 qa = *reinterpret_cast<const double4 *>(&recs[qbase + t]);   // this cloud's slice of the combined array
+    const double qx = qa.x, qy = qa.y, qz = qa.z;
+    const int qrow = (int)(__double_as_longlong(qa.w) & 0xffffffffll);
+    const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
+    const int cx = ncell_coord(qx, g.org[0], g.inv_h[0], dimx);
+    const int cy = ncell_coord(qy, g.org[1], g.inv_h[1], dimy);
+    const int cz = ncell_coord(qz, g.org[2], g.inv_h[2], dimz);
+    double bd[kKnnMax];
+    int bi[kKnnMax];
+    int cnt = 0;
+    bool done = false;
+    for (int r = 0; r <= kKnnMaxRing && !done; ++r) {
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, dimz - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, dimy - 1);
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const bool zface = (z == cz - r) || (z == cz + r);
+            for (int y = y0; y <= y1; ++y) {
+                const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
+                const bool full = zface || y == cy - r || y == cy + r;
+                for (int part = 0; part < (full ? 1 : 2); ++part) {
+                    int xa, xb;
+                    if (full) { xa = x0; xb = x1; }
+                    else if (part == 0) { xa = xb = cx - r; if (xa < 0) continue; }
+                    else { xa = xb = cx + r; if (xb > dimx - 1) continue; }
+                    const uint32_t s = cell_start[row + xa], e = cell_start[row + xb + 1];
+                    for (uint32_t p = s; p < e; ++p) {
+                        const double4 a = *reinterpret_cast<const double4 *>(&recs[p]);
+                        knn_insert(bd, bi, k, cnt, nd2(qx, qy, qz, a.x, a.y, a.z), (int)(__double_as_longlong(a.w) & 0xffffffffll));
+                    }
+                }
+            }
+        }
+        // stop rule of the grid engine, applied to the k-th best
+        double L = INFINITY;
+        const double q[3] = {qx, qy, qz};
+        const int c[3] = {cx, cy, cz};
+        for (int a = 0; a < 3; ++a) {
+            if (c[a] - r > 0) L = fmin(L, (q[a] - (g.org[a] + (double)(c[a] - r) * g.h[a])) - g.slack[a]);
+            if (c[a] + r < g.dim[a] - 1) L = fmin(L, ((g.org[a] + (double)(c[a] + r + 1) * g.h[a]) - q[a]) - g.slack[a]);
+        }
+        if (L == INFINITY) done = true;
+        else if (cnt == k && L > 0.0 && bd[k - 1] < L * L * (1.0 - 0x1.0p-30)) done = true;
+    }
+    if (done) {
+        normal_from_neighbours(x64, qx, qy, qz, bi, cnt, nrm_out + 3 * (int64_t)qrow);
+    } else {
+        open_list[atomicAdd(open_count, 1u)] = qrow;
+    }
+}
+
+// isolated points: exact k-NN by a full scan, one workgroup per point.  Every thread keeps the k best of its
+// stride; the k global best are then extracted one by one with a workgroup-wide lexicographic minimum.
+__global__ __launch_bounds__(256) void k_knn_normals_full(const double *__restrict__ x64, int64_t n, int k,
+                                                          const int32_t *__restrict__ open_list,
+                                                          const uint32_t *__restrict__ open_count,
+                                                          double *__restrict__ nrm_out)
+{
+    __shared__ double s_d[256];
+    __shared__ int s_i[256];
+    __shared__ int s_sel[kKnnMax];
+    const int tid = threadIdx.x;
+    const uint32_t count = *open_count;
+    for (uint32_t f = blockIdx.x; f < count; f += gridDim.x) {
+        const int qrow = open_list[f];
+        const double qx = x64[3 * (int64_t)qrow], qy = x64[3 * (int64_t)qrow + 1], qz = x64[3 * (int64_t)qrow + 2];
+        double bd[kKnnMax];
+        int bi[kKnnMax];
+        int cnt = 0;
+        for (int64_t j = tid; j < n; j += 256) knn_insert(bd, bi, k, cnt, nd2(qx, qy, qz, x64[3 * j], x64[3 * j + 1], x64[3 * j + 2]), (int)j);
+        int head = 0, nsel = 0;
+        const int want = n < k ? (int)n : k;
+        for (int round = 0; round < want; ++round) {
+            s_d[tid] = head < cnt ? bd[head] : INFINITY;
+            s_i[tid] = head < cnt ? bi[head] : 0x7fffffff;
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (tid < off) {
+                    const double od = s_d[tid + off];
+                    const int oi = s_i[tid + off];
+                    if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
+                }
+                __syncthreads();
+            }
+            const int win = s_i[0];
+            if (head < cnt && bi[head] == win) ++head;      // rows are unique: exactly one thread owns the winner
+            if (tid == 0) s_sel[nsel] = win;
+            ++nsel;
+            __syncthreads();
+        }
+        if (tid == 0) normal_from_neighbours(x64, qx, qy, qz, s_sel, nsel, nrm_out + 3 * (int64_t)qrow);
+        __syncthreads();
+    }
+}
+
+int estimate_normals(pccm_ctx *ctx, int which, int k)
+{
+    Cloud &c = ctx->cloud[which];
+    if (c.n <= 0) return fail(PCCM_E_STATE, "cloud %d is not set", which);
+    if (k < 3 || k > kKnnMax) return fail(PCCM_E_ARG, "k must be in 3..%d", kKnnMax);
+    int rc;
+    if ((rc = grid_ensure(ctx))) return rc;
+    const Grid &gr = ctx->grid;
+    KnnGeom g;
+    for (int a = 0; a < 3; ++a) {
+        g.dim[a] = gr.dim[a];
+        g.org[a] = gr.org[a];
+        g.h[a] = gr.h[a];
+        g.inv_h[a] = gr.inv_h[a];
+        g.slack[a] = (fabs(gr.org[a]) + (gr.dim[a] + 2) * gr.h[a]) * 0x1.0p-48;
+    }
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    if (c.nrm64 && c.n_nrm != c.n) {
+        PCCM_HIP(hipFree(c.nrm64));
+        c.nrm64 = nullptr;
+    }
+    if (!c.nrm64) PCCM_HIP(hipMalloc((void **)&c.nrm64, (size_t)c.n * 3 * sizeof(double)));
+    c.n_nrm = c.n;
+    for (int d = 0; d < 3; ++d) ctx->nn_gen[d]++;      // pending D2 reductions would use stale normals
+    ctx->epoch++;
+    if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)c.n * sizeof(uint32_t)))) return rc;   // reused as the open list
+    if ((rc = ensure(ctx, ctx->g_blocksum, 256))) return rc;
+    uint32_t *open_count = (uint32_t *)ctx->g_blocksum.p;
+    PCCM_HIP(hipMemsetAsync(open_count, 0, sizeof(uint32_t), ctx->stream));
+    // cell_start holds positions in the combined record array: pass the array base plus this cloud's offset
+    const uint32_t *cs = (const uint32_t *)gr.cell_start.p + (which ? gr.ncells + 1 : 0);
+    hipLaunchKernelGGL(k_knn_normals, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const GridRec *)gr.recs.p, (int64_t)(which ? gr.n[0] : 0), c.n, g, cs, (const double *)c.xyz64, k,
+                       c.nrm64, (int32_t *)ctx->g_cell_of.p, open_count);
+    hipLaunchKernelGGL(k_knn_normals_full, dim3(512), dim3(256), 0, ctx->stream, (const double *)c.xyz64, c.n, k,
+                       (const int32_t *)ctx->g_cell_of.p, (const uint32_t *)open_count, c.nrm64);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+}  // namespace pccm

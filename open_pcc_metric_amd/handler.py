@@ -6,8 +6,9 @@
 Extra, optional flags (defaults reproduce the reference): ``--device``, ``--engine``,
 ``--normal-index row|neighbour`` (row = the reference's D2, which raises IndexError when the clouds
 differ in size), ``--extent X Y Z`` (inject the PSNR peak box instead of the
-Qhull minimal-OBB restatement).  Point-to-plane needs normals in both files: the reference would call
-Open3D's estimate_normals (cloud_pair.py:61-64), which this package does not restate.
+Qhull minimal-OBB restatement).  Files without normals get them estimated on the GPU when
+--point-to-plane asks for them (k = 30 covariance normals, as Open3D's estimate_normals does at
+cloud_pair.py:61-64).
 """
 import click
 

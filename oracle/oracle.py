@@ -65,6 +65,8 @@ def _load():
     lib.orc_point_to_plane.argtypes = [c_dp, ctypes.c_int64, c_dp, c_ip, c_dp, ctypes.c_int64,
                                        ctypes.c_int, c_dp]
     lib.orc_point_to_plane.restype = ctypes.c_int
+    lib.orc_knn_brute.argtypes = [c_dp, ctypes.c_int64, c_dp, ctypes.c_int64, ctypes.c_int, c_ip]
+    lib.orc_knn_brute.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -138,6 +140,36 @@ def point_to_plane(iter_pts, search_pts, nn_idx, other_normals, *, normal_index:
     if rc != 0:
         raise RuntimeError(f"oracle point_to_plane failed rc={rc}")
     return out
+
+
+def knn(points, k: int) -> np.ndarray:
+    """(n, k) rows of the k nearest points of the cloud to each of its points (itself included)."""
+    p = _f64(points)
+    idx = np.empty((p.shape[0], k), dtype=np.int64)
+    rc = _load().orc_knn_brute(_dp(p), p.shape[0], _dp(p), p.shape[0], int(k), _ip(idx))
+    if rc != 0:
+        raise RuntimeError(f"oracle knn failed rc={rc}")
+    return idx
+
+
+def estimate_normals(points, k: int = 30):
+    """Restatement of Open3D's PointCloud.estimate_normals() defaults (cloud_pair.py:61-64): covariance of
+    the k nearest points (self included), eigenvector of the smallest eigenvalue.  Not pinned by the
+    reference (Open3D is absent); returns (normals, eigenvalues ascending) with unspecified sign."""
+    p = _f64(points)
+    n = p.shape[0]
+    kk = min(k, n)
+    nbr = knn(p, kk)
+    normals = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
+    evals = np.zeros((n, 3))
+    if kk < 3:
+        return normals, evals
+    d = p[nbr] - p[:, None, :]                              # (n, k, 3), relative to the query point
+    mean = d.mean(axis=1)
+    cov = np.einsum("nki,nkj->nij", d, d) / kk - mean[:, :, None] * mean[:, None, :]
+    w, v = np.linalg.eigh(cov)
+    normals = v[:, :, 0]
+    return normals, w
 
 
 class OraclePair:

@@ -270,3 +270,31 @@ int orc_point_to_plane(const double *iter_pts, int64_t n, const double *search_p
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * Exact k nearest neighbours by brute force (self included), ascending (d2, row); used to
+ * restate Open3D's estimate_normals() (cloud_pair.py:61-64; KDTreeSearchParamKNN(30)).
+ * idx: [nq][k] (rows padded with -1 when nr < k).
+ * ---------------------------------------------------------------------------------- */
+int orc_knn_brute(const double *q, int64_t nq, const double *r, int64_t nr, int k, int64_t *idx)
+{
+    if (k <= 0 || k > 256) return -1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
+    for (int64_t i = 0; i < nq; ++i) {
+        double bd[256];
+        int64_t bi[256];
+        int cnt = 0;
+        for (int64_t j = 0; j < nr; ++j) {
+            double d = orc_d2(q + 3 * i, r + 3 * j);
+            if (cnt == k && !(d < bd[k - 1])) continue;       /* j ascends: equal d never displaces */
+            int p = cnt < k ? cnt : k - 1;
+            while (p > 0 && d < bd[p - 1]) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; --p; }
+            bd[p] = d; bi[p] = j;
+            if (cnt < k) ++cnt;
+        }
+        for (int c = 0; c < k; ++c) idx[i * k + c] = c < cnt ? bi[c] : -1;
+    }
+    return 0;
+}
