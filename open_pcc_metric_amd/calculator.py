@@ -54,9 +54,11 @@ class MetricCalculator:
         done = self._calculated_metrics.get(key)
         if done is not None:
             return done
-        if isinstance(metric, PrimaryMetric):
+        role = getattr(metric, "_pccm_role", 0) or (1 if isinstance(metric, PrimaryMetric) else
+                                                    2 if isinstance(metric, SecondaryMetric) else 0)
+        if role == 1:
             metric.calculate(self._cloud_pair)
-        elif isinstance(metric, SecondaryMetric):
+        elif role == 2:
             resolved = {name: self._metric_recursive_calculate(dep)
                         for name, dep in metric._get_dependencies().items()}
             metric.calculate(**resolved)
@@ -82,7 +84,7 @@ class MetricCalculator:
                 wanted.append((m.is_left, m.point_to_plane))
             elif isinstance(m, BoundarySqrtDistances):
                 wanted.append("boundary")
-            if isinstance(m, SecondaryMetric):
+            if getattr(m, "_pccm_role", 0) == 2 or isinstance(m, SecondaryMetric):
                 stack.extend(m._get_dependencies().values())
         if wanted:
             prefetch(sorted(wanted, key=str))

@@ -590,7 +590,8 @@ int64_t pccm_xvec_len(int64_t n_iter)
 // consumes a slot (enqueuing it first when nobody prefetched it), so a caller that prefetches every
 // column it will need waits for the GPU once per step instead of once per column.
 // bookkeeping + buffers of one slot; the kernels are launched for all new slots together (slots_launch)
-static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int normal_mode, PointJobs &pj, UnitJobs &uj)
+static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int normal_mode, bool want_units, PointJobs &pj,
+                        UnitJobs &uj)
 {
     const Cloud *it, *se;
     NNResult *res;
@@ -616,10 +617,12 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     s.gen = ctx->nn_gen[dir];
     s.n_iter = it->n; s.begin = res->begin; s.end = res->end;
     s.nunits = ns > 0 ? (ns + kLeaf - 1) / kLeaf : 0;
+    s.nblocks = (s.nunits + 31) / 32;
+    s.has_units = want_units;
     const int64_t nfull = it->n / kChunk, full_rows = nfull * kChunk;
     s.t0 = res->begin > full_rows ? res->begin : full_rows;
     s.tail_n = s.t0 < res->end ? res->end - s.t0 : 0;
-    const size_t need = (size_t)(3 * s.nunits + s.tail_n + 1) * sizeof(double);
+    const size_t need = (size_t)(3 * s.nunits + 3 * s.nblocks + s.tail_n + 1) * sizeof(double);
     if (ctx->capturing && (need > s.host_cap || !s.ev)) {
         ctx->capture_failed = true;
         return fail(PCCM_E_STATE, "a reduction slot must be allocated during graph capture: run the sequence once first");
@@ -636,7 +639,10 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         UnitJob &U = uj.j[uj.njobs];
         U.val = dev; U.ns = ns; U.nunits = s.nunits;
         U.tail_first = s.t0 - res->begin; U.tail_n = s.tail_n;
-        U.out = s.host;
+        U.nblocks = s.nblocks;
+        U.out_units = want_units ? s.host : nullptr;
+        U.out_blocks = s.host + 3 * s.nunits;
+        U.out_tail = s.host + 3 * s.nunits + 3 * s.nblocks;
         const int64_t lanes = (s.nunits * 8 + 255) / 256 * 256;
         uj.uoff[uj.njobs + 1] = uj.uoff[uj.njobs] + lanes;
         uj.toff[uj.njobs + 1] = uj.toff[uj.njobs] + s.tail_n;
@@ -645,10 +651,10 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     return PCCM_OK;
 }
 
-static ReduceSlot *slot_find(pccm_ctx *ctx, int dir, int metric, int normal_mode)
+static ReduceSlot *slot_find(pccm_ctx *ctx, int dir, int metric, int normal_mode, bool need_units = false)
 {
     for (auto &s : ctx->slots)
-        if (s.pending && s.dir == dir && s.metric == metric && (metric == PCCM_METRIC_D1 || s.mode == normal_mode) &&
+        if (s.pending && (s.has_units || !need_units) && s.dir == dir && s.metric == metric && (metric == PCCM_METRIC_D1 || s.mode == normal_mode) &&
             s.gen == ctx->nn_gen[dir])
             return &s;
     return nullptr;
@@ -661,9 +667,17 @@ static ReduceSlot *slot_free(pccm_ctx *ctx)
     return &ctx->slots[0];
 }
 
+static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, bool want_units);
+
 int pccm_reduce_prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes)
 {
     CHECK_CTX(ctx);
+    // per-leaf results cross PCIe only when a sharded exchange will need them
+    return prefetch_many(ctx, n, dirs, metrics, normal_modes, ctx->world > 1);
+}
+
+static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, bool want_units)
+{
     if (n < 0 || n > 8 || (n > 0 && (!dirs || !metrics || !normal_modes))) return fail(PCCM_E_ARG, "1..8 requests expected");
     PointJobs pj;
     UnitJobs uj;
@@ -673,12 +687,12 @@ int pccm_reduce_prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *
     int nfresh = 0;
     for (int k = 0; k < n; ++k) {
         if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
-        if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k])) continue;
+        if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k], want_units)) continue;
         if (pj.njobs >= 4 && metrics[k] != PCCM_METRIC_D1) return fail(PCCM_E_ARG, "at most four point-to-plane columns per call");
         ReduceSlot *s = slot_free(ctx);
         if (s->pending && !ctx->capturing) PCCM_HIP(hipEventSynchronize(s->ev));
         s->pending = false;
-        int rc = slot_prepare(ctx, *s, dirs[k], metrics[k], normal_modes[k], pj, uj);
+        int rc = slot_prepare(ctx, *s, dirs[k], metrics[k], normal_modes[k], want_units, pj, uj);
         if (rc) return rc;
         s->pending = true;                 // so that slot_free/slot_find see it while the batch is assembled
         fresh[nfresh++] = s;
@@ -714,11 +728,11 @@ int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xve
     NOT_CAPTURING(ctx);
     if (!xvec || !minmax) return fail(PCCM_E_ARG, "null pointer");
     if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
-    ReduceSlot *s = slot_find(ctx, dir, metric, normal_mode);
+    ReduceSlot *s = slot_find(ctx, dir, metric, normal_mode, true);
     if (!s) {
-        int rc = pccm_reduce_prefetch(ctx, dir, metric, normal_mode);
+        int rc = prefetch_many(ctx, 1, &dir, &metric, &normal_mode, true);
         if (rc) return rc;
-        s = slot_find(ctx, dir, metric, normal_mode);
+        s = slot_find(ctx, dir, metric, normal_mode, true);
         if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
     }
     PCCM_HIP(hipEventSynchronize(s->ev));
@@ -738,7 +752,8 @@ int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xve
         if (umax[u] > minmax[1]) minmax[1] = umax[u];
     }
     if (s->tail_n > 0)   // raw values of the last, partial 8192-row chunk that fall into this shard
-        memcpy(xvec + nfull * (kChunk / kLeaf) + (s->t0 - full_rows), s->host + 3 * nunits, (size_t)s->tail_n * sizeof(double));
+        memcpy(xvec + nfull * (kChunk / kLeaf) + (s->t0 - full_rows), s->host + 3 * nunits + 3 * s->nblocks,
+               (size_t)s->tail_n * sizeof(double));
     return PCCM_OK;
 }
 
@@ -784,26 +799,26 @@ int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
     }
     PCCM_HIP(hipEventSynchronize(s->ev));
     s->pending = false;
-    const int64_t n = s->n_iter, nunits = s->nunits;
+    const int64_t n = s->n_iter, nunits = s->nunits, nblocks = s->nblocks;
     const int64_t nfull = n / kChunk;
-    const int lpc = kChunk / kLeaf;
-    const double *usum = s->host, *umin = usum + nunits, *umax = usum + 2 * nunits;
-    // np.sum: chunks of 8192 rows in sequence, each chunk = NumPy's pairwise tree over its 64 leaf sums
+    const double *bsum = s->host + 3 * nunits, *bmin = bsum + nblocks, *bmax = bsum + 2 * nblocks;
+    // np.sum: chunks of 8192 rows in sequence; each chunk = NumPy's pairwise tree = (tree of its first 32
+    // leaves) + (tree of its last 32 leaves), and the GPU already finished both halves (begin = 0 here)
     double total = 0.0;
     bool first = true;
     for (int64_t c = 0; c < nfull; ++c) {
-        const double cs = leaf_tree(usum + c * lpc, lpc);
+        const double cs = bsum[2 * c] + bsum[2 * c + 1];
         total = first ? cs : total + cs;
         first = false;
     }
     if (s->tail_n > 0) {
-        const double ts = np_pairwise_sum(s->host + 3 * nunits, s->tail_n);
+        const double ts = np_pairwise_sum(s->host + 3 * nunits + 3 * nblocks, s->tail_n);
         total = first ? ts : total + ts;
     }
     double mn = INFINITY, mx = -INFINITY;
-    for (int64_t u = 0; u < nunits; ++u) {
-        mn = umin[u] < mn ? umin[u] : mn;
-        mx = umax[u] > mx ? umax[u] : mx;
+    for (int64_t b = 0; b < nblocks; ++b) {
+        mn = bmin[b] < mn ? bmin[b] : mn;
+        mx = bmax[b] > mx ? bmax[b] : mx;
     }
     out[0] = total;
     out[1] = mn;
@@ -868,7 +883,8 @@ static int graph_replay(pccm_ctx *ctx, GraphRec &g)
             if (s.pending && s.gen == ctx->nn_gen[s.dir]) PCCM_HIP(hipEventSynchronize(s.ev));   // still in use by someone else
             s.dir = op.snap.dir; s.metric = op.snap.metric; s.mode = op.snap.mode;
             s.n_iter = op.snap.n_iter; s.begin = op.snap.begin; s.end = op.snap.end;
-            s.nunits = op.snap.nunits; s.t0 = op.snap.t0; s.tail_n = op.snap.tail_n;
+            s.nunits = op.snap.nunits; s.nblocks = op.snap.nblocks; s.has_units = op.snap.has_units;
+            s.t0 = op.snap.t0; s.tail_n = op.snap.tail_n;
             s.gen = ctx->nn_gen[s.dir];
             s.pending = true;
         }

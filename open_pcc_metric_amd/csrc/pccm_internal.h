@@ -75,9 +75,10 @@ struct ReduceSlot {            // one enqueued reduction (pccm_reduce_prefetch /
     bool pending = false;
     int dir = 0, metric = 0, mode = 0;
     uint64_t gen = 0;          // nn generation of `dir` it was computed from
-    int64_t n_iter = 0, begin = 0, end = 0, nunits = 0, t0 = 0, tail_n = 0;
+    int64_t n_iter = 0, begin = 0, end = 0, nunits = 0, nblocks = 0, t0 = 0, tail_n = 0;
+    bool has_units = false;    // per-leaf results were written (needed by pccm_reduce's exchange vector)
     DevBuf val, unit;
-    double *host = nullptr;    // pinned: [3][nunits] unit sums/min/max, then tail_n raw values
+    double *host = nullptr;    // pinned: [3][nunits] leaf sums/min/max | [3][nblocks] half-chunk trees | tail_n raw values
     size_t host_cap = 0;
     hipEvent_t ev = nullptr;
 };
@@ -185,7 +186,10 @@ struct UnitJob {                // one column to reduce (k_unit_jobs)
     const double *val;
     int64_t ns, nunits;
     int64_t tail_first, tail_n; // rows [tail_first, tail_first + tail_n) are copied out raw
-    double *out;                // pinned host memory: [3][nunits] sums/min/max, then tail_n raw values
+    int64_t nblocks;            // ceil(nunits / 32)
+    double *out_units;          // pinned host memory [3][nunits] per-leaf sum/min/max, or null
+    double *out_blocks;         // pinned host memory [3][nblocks] per-32-leaf tree sum/min/max
+    double *out_tail;           // pinned host memory [tail_n]
 };
 struct UnitJobs {
     UnitJob j[8];

@@ -261,20 +261,21 @@ int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs)
 
 __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
 {
+    __shared__ double ls[32], lmn[32], lmx[32];
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t unit_threads = jobs.uoff[jobs.njobs];
-    if (t < unit_threads) {
+    if (t < unit_threads) {                                // block-uniform: jobs start at multiples of 256 lanes
         int jb = 0;
 #pragma unroll
         for (int k = 1; k < 8; ++k)
             if (k < jobs.njobs && t >= jobs.uoff[k]) jb = k;
         const UnitJob &J = jobs.j[jb];
         const int64_t u = (t - jobs.uoff[jb]) >> 3;
-        const int k = threadIdx.x & 7;
-        if (u >= J.nunits) return;                 // padding lanes of a job (whole 8-lane groups)
+        const int k = threadIdx.x & 7, grp = threadIdx.x >> 3;
         const double *__restrict__ val = J.val;
         const int64_t base = u * kLeaf;
-        const int64_t cnt = (J.ns - base < kLeaf) ? J.ns - base : kLeaf;
+        const bool live = u < J.nunits;
+        const int64_t cnt = !live ? 0 : ((J.ns - base < kLeaf) ? J.ns - base : kLeaf);
         double r = 0.0, mn = INFINITY, mx = -INFINITY;
         if (cnt == kLeaf) {
             r = val[base + k];
@@ -301,9 +302,33 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
             mx = fmax(mx, __shfl_xor(mx, off));
         }
         if (k == 0) {
-            J.out[u] = r;
-            J.out[J.nunits + u] = mn;
-            J.out[2 * J.nunits + u] = mx;
+            if (live && J.out_units) {                     // per-leaf results: the sharded exchange needs them
+                J.out_units[u] = r;
+                J.out_units[J.nunits + u] = mn;
+                J.out_units[2 * J.nunits + u] = mx;
+            }
+            ls[grp] = r;
+            lmn[grp] = mn;
+            lmx[grp] = mx;
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            // this block's 32 leaves = one half of an 8192-row NumPy chunk when the shard starts on a chunk
+            // boundary: finish NumPy's pairwise tree for the half here (adjacent pairs, five levels), so the
+            // host only adds 2 numbers per chunk instead of walking 64 leaves
+            double s = ls[threadIdx.x], a = lmn[threadIdx.x], b = lmx[threadIdx.x];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                s = __dadd_rn(s, __shfl_xor(s, off));
+                a = fmin(a, __shfl_xor(a, off));
+                b = fmax(b, __shfl_xor(b, off));
+            }
+            if (threadIdx.x == 0) {
+                const int64_t blk = (t - jobs.uoff[jb]) >> 8;
+                J.out_blocks[blk] = s;
+                J.out_blocks[J.nblocks + blk] = a;
+                J.out_blocks[2 * J.nblocks + blk] = b;
+            }
         }
         return;
     }
@@ -316,7 +341,7 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
         if (k < jobs.njobs && c >= jobs.toff[k]) jb = k;
     const UnitJob &J = jobs.j[jb];
     const int64_t e = c - jobs.toff[jb];
-    J.out[3 * J.nunits + e] = J.val[J.tail_first + e];
+    J.out_tail[e] = J.val[J.tail_first + e];
 }
 
 int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)

@@ -37,12 +37,16 @@ class AbstractMetric(abc.ABC):                       # metric.py:14-29
 
 
 class PrimaryMetric(AbstractMetric):                 # metric.py:32-38 -- reads the CloudPair
+    _pccm_role = 1          # what the calculator dispatches on (an isinstance on an ABC costs ~1 us)
+
     @abc.abstractmethod
     def calculate(self, cloud_pair: CloudPair) -> None:
         raise NotImplementedError("calculate is not implemented")
 
 
 class SecondaryMetric(AbstractMetric):               # metric.py:41-50 -- pure function of its deps
+    _pccm_role = 2
+
     def _get_dependencies(self) -> typing.Dict[str, "AbstractMetric"]:
         return {}
 
@@ -58,7 +62,7 @@ class DirectionalMetric(AbstractMetric):             # metric.py:53-60
         self.is_left = is_left
 
     def _key(self) -> typing.Tuple:
-        return super()._key() + (self.is_left,)
+        return (type(self).__name__, self.is_left)
 
 
 class PointToPlaneable(DirectionalMetric):           # metric.py:63-71
@@ -69,7 +73,7 @@ class PointToPlaneable(DirectionalMetric):           # metric.py:63-71
         self.point_to_plane = point_to_plane
 
     def _key(self) -> typing.Tuple:
-        return super()._key() + (self.point_to_plane,)
+        return (type(self).__name__, self.is_left, self.point_to_plane)
 
 
 def _side(metric: DirectionalMetric, left, right):
@@ -231,7 +235,7 @@ class ColorMetric(DirectionalMetric):                            # metric.py:250
         self.color_scheme = color_scheme
 
     def _key(self) -> typing.Tuple:
-        return super()._key() + (self.color_scheme,)
+        return (type(self).__name__, self.is_left, self.color_scheme)
 
 
 _FROM_RGB = {                                                    # metric.py:270-281
@@ -317,7 +321,7 @@ class SymmetricMetric(SecondaryMetric):                          # metric.py:446
         return {"lmetric": self.metrics[0], "rmetric": self.metrics[1]}
 
     def _key(self) -> typing.Tuple:
-        return super()._key() + self.metrics[0]._key() + self.metrics[1]._key()
+        return (type(self).__name__,) + self.metrics[0]._key() + self.metrics[1]._key()
 
     def calculate(self, lmetric: AbstractMetric, rmetric: AbstractMetric) -> None:
         # quality-like metrics (PSNR) report the worse = smaller side, error-like the larger;
