@@ -21,7 +21,8 @@
 //   query   k_grid_query_coop (ring 1, fp32 in LDS, fp64 certification; both directions)
 //           -> k_grid_tail_wave (few unsettled queries: one wave each, rings 1..kMaxRing)
 //           -> k_grid_query (many unsettled queries, e.g. lattice data: one thread each)
-//           -> k2b_fallback of the brute engine (still unsettled after kMaxRing rings)
+//           (both finish what kMaxRing rings cannot settle with a wave-cooperative exact scan of the
+//            whole searched cloud: wave_rescan)
 //
 // Exactness of the stop rule.  cell(x) = clamp(floor((x - org) * inv_h)) is monotonic in x, so a
 // point in a cell left of cell c lies below org + c*h up to a few ulps of the grid's size; the
@@ -235,9 +236,10 @@ struct QueryJob {
     int32_t *idx_out;
     double *d2_out;
     GridRec *tail;              // queries ring 1 could not settle
-    int32_t *flagged;           // queries for the brute engine's exact rescan
-    float *flag_thr;
-    uint32_t *counters;         // [0] = number flagged, [1] = tail length
+    uint32_t *counters;         // [0] = queries that needed the exact full rescan, [1] = tail length
+    const float *r32;           // searched cloud, fp32 quad layout (pccm_brute.hip) and fp64 rows: full rescan
+    const double *r64;
+    int64_t nr;
 };
 
 struct QueryJobs {
@@ -300,16 +302,42 @@ __device__ __forceinline__ bool settled_by(double L, double d)
     return (L == INFINITY) || (L > 0.0 && d < L * L * (1.0 - 0x1.0p-30));
 }
 
-__device__ __forceinline__ void flag_for_rescan(const QueryJob &J, int qrow, double best)
+// Exact answer for ONE query by a scan of the whole searched cloud, done by the 64 lanes of the calling
+// wave together (all lanes must call it with the same, wave-uniform arguments).  Same filter as the brute
+// engine's k2b_fallback: every possible fp64 winner has d32 <= thr(best found so far), so only those are
+// evaluated in fp64; lexicographic (d2, row) minimum.  Reached by queries that kMaxRing rings could not
+// settle (isolated outliers, disjoint clouds).
+template <bool SELF>
+__device__ void wave_rescan(const QueryJob &J, double qx, double qy, double qz, int qrow, double best, Best &out)
 {
-    // every possible winner has d32 <= thr(best so far) -- same bound as k2_refine
+    const int lane = threadIdx.x & 63;
     double tq = (best == INFINITY) ? 1.0e18 : sqrt(best) * (1.0 + 0x1.0p-20) + J.slack32;
     double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
     float tf = thr > 3.0e38 ? 3.0e38f : (float)thr;
     tf = __uint_as_float(__float_as_uint(tf) + 1u);
-    const uint32_t pos = atomicAdd(&J.counters[0], 1u);
-    J.flagged[pos] = (int32_t)(qrow - J.row_base);
-    J.flag_thr[pos] = tf;
+    const float fx = (float)qx, fy = (float)qy, fz = (float)qz;
+    Best b;
+    b.d = INFINITY;
+    b.idx = 0x7fffffff;
+    for (int64_t j = lane; j < J.nr; j += 64) {
+        const float *qd = J.r32 + (j >> 2) * 12 + (j & 3);
+        const float ax = fx - qd[0], ay = fy - qd[4], az = fz - qd[8];
+        float d = ax * ax;
+        d = __builtin_fmaf(ay, ay, d);
+        d = __builtin_fmaf(az, az, d);
+        if (d <= tf && !(SELF && j == qrow)) {
+            const double e = gdist64(qx, qy, qz, J.r64[3 * j], J.r64[3 * j + 1], J.r64[3 * j + 2]);
+            if (e < b.d) { b.d = e; b.idx = (int)j; }        // j ascends per lane: the first hit is the smallest row
+        }
+    }
+    double wm = b.d;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wm = fmin(wm, __shfl_xor(wm, off));
+    int wi = (b.d == wm) ? b.idx : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wi = min(wi, __shfl_xor(wi, off));
+    out.d = wm;
+    out.idx = wi;
 }
 
 // ---- per-thread ring search: the long-tail kernel (and the whole query when PCCM_GRID_COOP=0) --------------
@@ -329,8 +357,10 @@ __global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g, 
         }
         const uint32_t *__restrict__ cell_start = J.cs;
         const GridRec *__restrict__ srecs = J.srecs;
-        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nq; t += (int64_t)gridDim.x * 256) {
-            const double4 qa = *reinterpret_cast<const double4 *>(&qrecs[t]);
+        for (int64_t t0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); t0 < nq; t0 += (int64_t)gridDim.x * 256) {
+            const int64_t t = t0 + (threadIdx.x & 63);
+            const bool live = t < nq;                        // dead lanes ride along (wave-cooperative tail below)
+            const double4 qa = *reinterpret_cast<const double4 *>(&qrecs[live ? t : nq - 1]);
             const double qx = qa.x, qy = qa.y, qz = qa.z;
             const int qrow = rec_row(qa);
             const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
@@ -339,8 +369,8 @@ __global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g, 
             Best b;
             b.d = INFINITY;
             b.idx = 0x7fffffff;
-            bool done = false;
-            {
+            bool done = !live;
+            if (live) {
                 // ring 1 = the 3x3x3 block: nine x-runs whose bounds are fetched together up front
                 const int x0 = max(cx - 1, 0), x1 = min(cx + 1, dimx - 1);
                 uint32_t rs[9], re[9];
@@ -378,12 +408,25 @@ __global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g, 
                 }
                 done = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, r), b.d);
             }
-            if (done) {
+            if (done && live) {
                 if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }   // SELF on a one-point cloud (host handles it earlier)
                 J.idx_out[qrow - J.row_base] = b.idx;
                 J.d2_out[qrow - J.row_base] = b.d;
-            } else {
-                flag_for_rescan(J, qrow, b.d);
+            }
+            // lanes still open after kMaxRing rings: the wave finishes them one at a time, all lanes scanning
+            // (the loop above keeps whole waves together: t advances by the grid size for every lane)
+            unsigned long long open = __ballot(!done);
+            while (open) {
+                const int l = __ffsll((long long)open) - 1;
+                open &= open - 1;
+                Best r;
+                wave_rescan<SELF>(J, __shfl(qx, l), __shfl(qy, l), __shfl(qz, l), __shfl(qrow, l), __shfl(b.d, l), r);
+                if ((threadIdx.x & 63) == l) {
+                    if (r.idx == 0x7fffffff) { r.idx = -1; r.d = 0.0; }
+                    J.idx_out[qrow - J.row_base] = r.idx;
+                    J.d2_out[qrow - J.row_base] = r.d;
+                    atomicAdd(&J.counters[0], 1u);
+                }
             }
         }
     }
@@ -645,14 +688,14 @@ __global__ __launch_bounds__(256) void k_grid_tail_wave(QueryJobs jobs, GridGeom
                 b.idx = wi;
                 done = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, r), b.d);
             }
+            if (!done) {                                     // wave-uniform
+                wave_rescan<SELF>(J, qx, qy, qz, qrow, b.d, b);
+                if (lane == 0) atomicAdd(&J.counters[0], 1u);
+            }
             if (lane == 0) {
-                if (done) {
-                    if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }
-                    J.idx_out[qrow - J.row_base] = b.idx;
-                    J.d2_out[qrow - J.row_base] = b.d;
-                } else {
-                    flag_for_rescan(J, qrow, b.d);
-                }
+                if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }
+                J.idx_out[qrow - J.row_base] = b.idx;
+                J.d2_out[qrow - J.row_base] = b.d;
             }
         }
     }
@@ -863,8 +906,6 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         const int si = (dir == PCCM_DIR_LEFT) ? 1 : 0;      // searched cloud
         const int ii = (dir == PCCM_DIR_RIGHT) ? 1 : 0;     // iterating cloud
         const Cloud &it = ctx->cloud[ii], &se = ctx->cloud[si];
-        if ((rc = ensure(ctx, res.flagged, (size_t)nq * sizeof(int32_t)))) return rc;
-        if ((rc = ensure(ctx, res.flag_thr, (size_t)nq * sizeof(float)))) return rc;
         if ((rc = ensure(ctx, res.tail, (size_t)nq * sizeof(GridRec)))) return rc;
         QueryJob J;
         if (res.begin == 0 && res.end == it.n) {
@@ -892,9 +933,10 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         J.idx_out = res.idx;
         J.d2_out = res.d2;
         J.tail = (GridRec *)res.tail.p;
-        J.flagged = (int32_t *)res.flagged.p;
-        J.flag_thr = (float *)res.flag_thr.p;
-        J.counters = res.nflag_dev;                         // [0] flagged, [1] tail length
+        J.counters = res.nflag_dev;                         // [0] full rescans, [1] tail length
+        J.r32 = (const float *)se.xyz32;
+        J.r64 = se.xyz64;
+        J.nr = se.n;
         PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
         QueryJobs &dst = (dir == PCCM_DIR_SELF) ? selfj : normal;
         dst.j[dst.njobs++] = J;
@@ -934,13 +976,6 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
             else hipLaunchKernelGGL((k_grid_query<false>), grid, dim3(256), 0, ctx->stream, jobs, g, 0);
         }
         PCCM_HIP(hipGetLastError());
-    }
-    for (int d = 0; d < ndirs; ++d) {
-        const int dir = dirs[d];
-        NNResult &res = ctx->nn[dir];
-        if (res.end - res.begin <= 0) continue;
-        const int si = (dir == PCCM_DIR_LEFT) ? 1 : 0, ii = (dir == PCCM_DIR_RIGHT) ? 1 : 0;
-        if ((rc = launch_fallback(ctx, ctx->cloud[ii], ctx->cloud[si], dir == PCCM_DIR_SELF, res))) return rc;
     }
     return PCCM_OK;
 }

@@ -42,6 +42,11 @@ def clouds(kind, na, nb, seed):
         a = np.unique(np.round(p).astype(np.float32), axis=0)[:na]
         b = np.unique(np.round(a + rng.normal(0, 0.7, a.shape)).astype(np.float32), axis=0)[:nb]
         return a, b
+    if kind == "disjoint":      # two clouds far apart plus a few stragglers: ring search cannot settle, exact full scans
+        a = rng.random((na, 3))
+        b = rng.random((nb, 3)) * np.array([1.0, 1.0, 0.02]) + np.array([30.0, -12.0, 55.0])
+        a[:5] += 400.0
+        return a, b
     if kind == "far":
         return (rng.random((na, 3)) * 1e6 + 1e9), (rng.random((nb, 3)) * 1e6 + 1e9)
     raise ValueError(kind)
@@ -62,7 +67,7 @@ def engine():
 CASES = [("uniform32", 5, 7), ("uniform32", 1, 1), ("uniform32", 2, 1), ("uniform32", 1000, 1000),
          ("uniform32", 1023, 1025), ("uniform32", 4097, 2049), ("f64", 3000, 2500), ("lattice", 2000, 2000),
          ("voxel10", 5000, 4000), ("dup", 600, 500), ("far", 800, 900), ("uniform32", 70000, 65537),
-         ("surface", 60000, 60000)]
+         ("surface", 60000, 60000), ("disjoint", 3000, 2500)]
 
 
 @pytest.mark.parametrize("engine_name", ENGINES)
