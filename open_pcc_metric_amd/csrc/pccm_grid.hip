@@ -19,8 +19,8 @@
 // "jobs", because at these sizes the kernels are latency-bound and launches cost ~5 us each):
 //   build   k_grid_cells (cell id + rank by atomicAdd, both clouds) -> exclusive scan -> k_grid_scatter
 //   query   k_grid_query_coop (ring 1, fp32 in LDS, fp64 certification; both directions)
-//           -> k_grid_tail_wave (few unsettled queries: one wave each, rings 1..kMaxRing)
-//           -> k_grid_query (many unsettled queries, e.g. lattice data: one thread each)
+//           -> k_grid_finish: few unsettled queries one wave each (wave_tail), many (e.g. lattice data
+//              without the TIES kernel) one thread each (thread_search), rings 1..kMaxRing
 //           (both finish what kMaxRing rings cannot settle with a wave-cooperative exact scan of the
 //            whole searched cloud: wave_rescan)
 //
@@ -342,9 +342,9 @@ __device__ void wave_rescan(const QueryJob &J, double qx, double qy, double qz, 
 
 // ---- per-thread ring search: the long-tail kernel (and the whole query when PCCM_GRID_COOP=0) --------------
 // One query per thread, rings 1..kMaxRing.  from_tail: the queries are the job's tail list and the kernel
-// only runs when that list is too long for k_grid_tail_wave.
+// only runs when that list is too long for wave_tail.
 template <bool SELF>
-__global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g, int from_tail)
+__device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridGeom &g, int from_tail)
 {
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
     for (int jb = 0; jb < jobs.njobs; ++jb) {
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g, 
         int64_t nq = J.nq;
         if (from_tail) {
             nq = (int64_t)J.counters[1];
-            if (nq <= (int64_t)kTailWaveMax) continue;      // short tail: k_grid_tail_wave handled it
+            if (nq <= (int64_t)kTailWaveMax) continue;      // short tail: wave_tail handled it
         }
         const uint32_t *__restrict__ cell_start = J.cs;
         const GridRec *__restrict__ srecs = J.srecs;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
 // (the minimum is idempotent).  Long tails (lattice data, where exact ties defeat the fp32
 // certification) go through k_grid_query instead, which has the parallelism then.
 template <bool SELF>
-__global__ __launch_bounds__(256) void k_grid_tail_wave(QueryJobs jobs, GridGeom g)
+__device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom &g)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
@@ -699,6 +699,22 @@ __global__ __launch_bounds__(256) void k_grid_tail_wave(QueryJobs jobs, GridGeom
             }
         }
     }
+}
+
+// one launch finishes whatever the cooperative kernel left open: short tails wave-per-query, long tails
+// thread-per-query (each checks the tail length on the device and does nothing when it is not its case)
+template <bool SELF>
+__global__ __launch_bounds__(256) void k_grid_finish(QueryJobs jobs, GridGeom g)
+{
+    wave_tail<SELF>(jobs, g);
+    thread_search<SELF>(jobs, g, 1);
+}
+
+// the whole query by the per-thread search (PCCM_GRID_COOP=0; A/B reference for the cooperative kernel)
+template <bool SELF>
+__global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g)
+{
+    thread_search<SELF>(jobs, g, 0);
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -898,6 +914,17 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
     QueryJobs normal, selfj;
     normal.njobs = 0;
     selfj.njobs = 0;
+    // the directions' counter pairs {rescans, tail length} live side by side: one memset covers this call's
+    int dlo = 2, dhi = 0;
+    for (int d = 0; d < ndirs; ++d) {
+        dlo = dirs[d] < dlo ? dirs[d] : dlo;
+        dhi = dirs[d] > dhi ? dirs[d] : dhi;
+    }
+    if (ndirs > 0 && dhi - dlo + 1 == ndirs)
+        PCCM_HIP(hipMemsetAsync((uint32_t *)ctx->counters.p + 2 * dlo, 0, (size_t)2 * ndirs * sizeof(uint32_t), ctx->stream));
+    else
+        for (int d = 0; d < ndirs; ++d)
+            PCCM_HIP(hipMemsetAsync(ctx->nn[dirs[d]].nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
     for (int d = 0; d < ndirs; ++d) {
         const int dir = dirs[d];
         NNResult &res = ctx->nn[dir];
@@ -937,7 +964,6 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         J.r32 = (const float *)se.xyz32;
         J.r64 = se.xyz64;
         J.nr = se.n;
-        PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
         QueryJobs &dst = (dir == PCCM_DIR_SELF) ? selfj : normal;
         dst.j[dst.njobs++] = J;
         res.stats[1] = 0;
@@ -957,23 +983,20 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         dim3 tgrid((unsigned)((nqmax + 255) / 256));     // long tails need the whole grid; idle blocks just exit
         if (use_coop()) {
             dim3 grid((unsigned)((chunks + 3) / 4));
-            dim3 wgrid((unsigned)(nqmax < 4096 ? (nqmax + 3) / 4 : 1024));
             const bool ties = ctx->cloud[0].all_int && ctx->cloud[1].all_int;
             if (self) {
                 if (ties) hipLaunchKernelGGL((k_grid_query_coop<true, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 else hipLaunchKernelGGL((k_grid_query_coop<true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                hipLaunchKernelGGL((k_grid_tail_wave<true>), wgrid, dim3(256), 0, ctx->stream, jobs, g);
-                hipLaunchKernelGGL((k_grid_query<true>), tgrid, dim3(256), 0, ctx->stream, jobs, g, 1);
+                hipLaunchKernelGGL((k_grid_finish<true>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
             } else {
                 if (ties) hipLaunchKernelGGL((k_grid_query_coop<false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 else hipLaunchKernelGGL((k_grid_query_coop<false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                hipLaunchKernelGGL((k_grid_tail_wave<false>), wgrid, dim3(256), 0, ctx->stream, jobs, g);
-                hipLaunchKernelGGL((k_grid_query<false>), tgrid, dim3(256), 0, ctx->stream, jobs, g, 1);
+                hipLaunchKernelGGL((k_grid_finish<false>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
             }
         } else {
             dim3 grid((unsigned)((nqmax + 255) / 256));
-            if (self) hipLaunchKernelGGL((k_grid_query<true>), grid, dim3(256), 0, ctx->stream, jobs, g, 0);
-            else hipLaunchKernelGGL((k_grid_query<false>), grid, dim3(256), 0, ctx->stream, jobs, g, 0);
+            if (self) hipLaunchKernelGGL((k_grid_query<true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+            else hipLaunchKernelGGL((k_grid_query<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
         }
         PCCM_HIP(hipGetLastError());
     }
