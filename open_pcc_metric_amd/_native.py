@@ -299,6 +299,11 @@ class Engine:
         _check(self._lib.pccm_graph_end(self._ctx, ctypes.byref(gid)))
         return int(gid.value)
 
+    def graph_abort(self) -> None:
+        """Leave capture mode after a captured call failed (the partial graph is discarded)."""
+        gid = ctypes.c_int(-1)
+        self._lib.pccm_graph_end(self._ctx, ctypes.byref(gid))      # reports the failure; nothing to keep
+
     def graph_launch(self, graph_id: int) -> None:
         _check(self._lib.pccm_graph_launch(self._ctx, int(graph_id)))
 

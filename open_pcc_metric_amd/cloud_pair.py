@@ -238,7 +238,9 @@ class CloudPair:
                     self._graph_id = eng.graph_end()
                     self._self_done = wants_self
                     return
-                except RuntimeError:
+                except (RuntimeError, ValueError, IndexError):
+                    eng.graph_abort()                         # leave capture mode; results were invalidated
+                    self._graph_id = None
                     self._use_graph = False                   # capture not possible here: stay eager
         self._enqueue_sweeps()
         self._self_done = False

@@ -1,0 +1,136 @@
+"""Edge cases of the GPU path: degenerate geometry, skewed sizes, large offsets, duplicates, hipGraph
+capture/replay semantics.  Everything is compared bit for bit with the CPU oracle."""
+import numpy as np
+import pytest
+
+from open_pcc_metric_amd import _native as nat
+from open_pcc_metric_amd.calculator import MetricCalculator
+from open_pcc_metric_amd.cloud_pair import CloudPair
+from open_pcc_metric_amd.options import CalculateOptions, transform_options
+from open_pcc_metric_amd.point_cloud import PointCloud
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = nat.Engine(0)
+    yield e
+    e.close()
+
+
+def assert_all_directions(engine, a, b, engines=("grid", "brute")):
+    a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    engine.set_cloud(0, a)
+    engine.set_cloud(1, b)
+    for name in engines:
+        for d, (q, r, skip) in enumerate(((a64, b64, False), (b64, a64, False), (a64, a64, True))):
+            engine.nn(d, name)
+            idx, d2 = engine.fetch_nn(d)
+            if skip and len(a64) < 2:
+                assert np.all(idx == -1) and np.all(d2 == 0)
+                continue
+            oi, od = orc.nn(q, r, skip_same_index=skip, method="kdtree")
+            assert np.array_equal(d2, od), (name, d)
+            assert np.array_equal(idx, oi), (name, d)
+
+
+def test_planar_and_collinear_clouds(engine):
+    rng = np.random.default_rng(1)
+    plane_a = rng.random((4000, 3)); plane_a[:, 2] = 0.25
+    plane_b = rng.random((3500, 3)); plane_b[:, 2] = 0.25
+    assert_all_directions(engine, plane_a, plane_b)
+    line_a = np.zeros((3000, 3)); line_a[:, 0] = rng.random(3000)
+    line_b = np.zeros((2000, 3)); line_b[:, 0] = rng.random(2000); line_b[:, 1] = 1e-3
+    assert_all_directions(engine, line_a, line_b)
+
+
+def test_all_points_identical_and_heavy_duplicates(engine):
+    same = np.tile(np.array([[1.5, -2.0, 3.25]]), (2000, 1))
+    assert_all_directions(engine, same, same[:1500])
+    rng = np.random.default_rng(2)
+    base = rng.random((50, 3), dtype=np.float32)
+    a = base[rng.integers(0, 50, 5000)]                       # 100 copies of each of 50 points
+    b = base[rng.integers(0, 50, 4000)] + np.float32(1e-3)
+    assert_all_directions(engine, a, b)
+
+
+def test_skewed_sizes(engine):
+    rng = np.random.default_rng(3)
+    assert_all_directions(engine, rng.random((200000, 3), dtype=np.float32), rng.random((37, 3), dtype=np.float32), engines=("grid",))
+    assert_all_directions(engine, rng.random((1, 3)), rng.random((50000, 3)), engines=("grid",))
+
+
+def test_large_offsets_and_scales(engine):
+    rng = np.random.default_rng(4)
+    a = rng.random((6000, 3)) * 1e-6 + 1e9                    # fp64 detail far below fp32 resolution
+    b = a[rng.integers(0, 6000, 5000)] + rng.normal(0, 1e-7, (5000, 3))
+    assert_all_directions(engine, a, b)
+    a = (rng.random((5000, 3)) - 0.5) * 1e12
+    b = (rng.random((5000, 3)) - 0.5) * 1e12
+    assert_all_directions(engine, a, b)
+    a = rng.random((5000, 3)) * 1e-30
+    b = rng.random((5000, 3)) * 1e-30
+    assert_all_directions(engine, a, b)
+
+
+def test_clusters_with_voids(engine):
+    rng = np.random.default_rng(5)
+    centers = rng.random((6, 3)) * 100
+    a = np.concatenate([c + rng.normal(0, 0.05, (2000, 3)) for c in centers])
+    b = np.concatenate([c + rng.normal(0, 0.05, (1500, 3)) for c in centers[:4]])   # two clusters have no partner
+    assert_all_directions(engine, a, b)
+
+
+def test_graph_capture_replay_and_staleness(engine):
+    rng = np.random.default_rng(6)
+    a, b = rng.random((30000, 3), dtype=np.float32), rng.random((31000, 3), dtype=np.float32)
+    engine.set_cloud(0, a)
+    engine.set_cloud(1, b)
+    engine.graph_begin()
+    with pytest.raises(RuntimeError):                         # nothing ran yet: capture cannot allocate
+        engine.nn_pair("grid")
+    with pytest.raises(RuntimeError):                         # ... and the capture reports it was abandoned
+        engine.graph_end()
+    engine.drop_caches(); engine.nn_pair("grid"); engine.reduce_prefetch_many([(0, 0), (1, 0)])
+    want = [engine.reduce_total(d, 0) for d in (0, 1)]
+    engine.graph_begin()
+    engine.drop_caches(); engine.nn_pair("grid"); engine.reduce_prefetch_many([(0, 0), (1, 0)])
+    gid = engine.graph_end()
+    assert [engine.reduce_total(d, 0) for d in (0, 1)] == want
+    for _ in range(3):
+        engine.graph_launch(gid)
+        assert [engine.reduce_total(d, 0) for d in (0, 1)] == want
+        idx, d2 = engine.fetch_nn(1)
+        oi, od = orc.nn(b.astype(np.float64), a.astype(np.float64), method="kdtree")
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+    engine.graph_begin()
+    with pytest.raises(RuntimeError):                         # fetch is not a capturable call
+        engine.fetch_nn(0)
+    engine.graph_abort()
+    engine.set_cloud(1, a[:1000])                             # new input: the recorded graph is stale
+    with pytest.raises((RuntimeError, ValueError)):
+        engine.graph_launch(gid)
+    engine.nn_pair("grid")                                    # and the context still works
+    idx, d2 = engine.fetch_nn(0)
+    oi, od = orc.nn(a.astype(np.float64), a[:1000].astype(np.float64), method="kdtree")
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+
+
+def test_recompute_with_graph_matches_eager():
+    rng = np.random.default_rng(7)
+    a, b = rng.random((20000, 3), dtype=np.float32), rng.random((20000, 3), dtype=np.float32)
+    na, nb = rng.standard_normal((20000, 3)), rng.standard_normal((20000, 3))
+    opts = CalculateOptions(None, True, True)
+    eager = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1])
+    want = MetricCalculator(eager).calculate(transform_options(opts)).as_dict()
+    pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], use_graph=True)
+    for _ in range(5):                                        # eager, capture, replays
+        pair.recompute()
+        got = MetricCalculator(pair).calculate(transform_options(opts)).as_dict()
+        assert got == want
+    assert pair._graph_id is not None
+    MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, False, False)))   # a different report
+    pair.recompute()
+    assert MetricCalculator(pair).calculate(transform_options(opts)).as_dict() == want
