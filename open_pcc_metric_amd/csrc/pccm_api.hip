@@ -239,13 +239,12 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
     for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
-    DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->unit, &ctx->stats, &ctx->staging,
+    DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->stats, &ctx->staging,
                       &ctx->counters};
     for (DevBuf *b : bufs) free_buf(*b);
     for (auto &g : ctx->graphs) graph_free(g);
     for (auto &s : ctx->slots) {
         free_buf(s.val);
-        free_buf(s.unit);
         if (s.host) (void)hipHostFree(s.host);
         if (s.ev) (void)hipEventDestroy(s.ev);
     }

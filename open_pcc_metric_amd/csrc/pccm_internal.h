@@ -77,7 +77,7 @@ struct ReduceSlot {            // one enqueued reduction (pccm_reduce_prefetch /
     uint64_t gen = 0;          // nn generation of `dir` it was computed from
     int64_t n_iter = 0, begin = 0, end = 0, nunits = 0, nblocks = 0, t0 = 0, tail_n = 0;
     bool has_units = false;    // per-leaf results were written (needed by pccm_reduce's exchange vector)
-    DevBuf val, unit;
+    DevBuf val;
     double *host = nullptr;    // pinned: [3][nunits] leaf sums/min/max | [3][nblocks] half-chunk trees | tail_n raw values
     size_t host_cap = 0;
     hipEvent_t ev = nullptr;
@@ -112,10 +112,9 @@ struct pccm_ctx {
     int rank = 0, world = 1;
     pccm::NNResult nn[3];
     // scratch
-    pccm::DevBuf part_b1, part_g, part_b2, val, unit, stats, staging, counters;
+    pccm::DevBuf part_b1, part_g, part_b2, val, stats, staging, counters;
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum;   // grid-engine scratch
-    std::vector<double> host_unit;
     pccm::ReduceSlot slots[8];
     uint64_t nn_gen[3] = {1, 1, 1};
     // hipGraph capture of a step (pccm_graph_*): epoch changes whenever inputs, shard or any device
@@ -202,8 +201,6 @@ int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs);
 
 int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,
                         int normal_mode, double *out_val /*[ns]*/, double *out_err /*[ns][3] or null*/);
-// per-unit (128 rows) sums/min/max of val[0..ns): unit_out = [3][nunits] (sum, min, max)
-int launch_unit_reduce(pccm_ctx *ctx, const double *val, int64_t ns, double *unit_out, int64_t nunits);
 
 double np_pairwise_sum(const double *a, int64_t n);
 

@@ -165,63 +165,10 @@ int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const N
 }
 
 // ------------------------------------------------------------------------------------------
-// K5: per-unit (128 rows) sum / min / max.  Eight lanes per unit; lane k accumulates rows
-// k, k+8, k+16, ... in order and the eight accumulators are combined as
-// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) -- exactly NumPy's pairwise-sum leaf, so that the host
-// can finish np.sum's tree bit for bit (pccm_finish_sum).
+// K5 (k_unit_jobs below): per 128-row leaf, eight lanes accumulate rows k, k+8, k+16, ... in order and
+// the eight accumulators are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) -- exactly NumPy's
+// pairwise-sum leaf, so that np.sum's tree can be finished bit for bit (pccm_finish_sum / pccm_reduce_total).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_unit_reduce(const double *__restrict__ val, int64_t ns,
-                                                     double *__restrict__ usum, double *__restrict__ umin,
-                                                     double *__restrict__ umax, int64_t nunits)
-{
-    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
-    const int k = threadIdx.x & 7;
-    if (u >= nunits) return;   // whole 8-lane groups leave together
-    const int64_t base = u * kLeaf;
-    const int64_t cnt = (ns - base < kLeaf) ? ns - base : kLeaf;
-    double r = 0.0, mn = INFINITY, mx = -INFINITY;
-    if (cnt == kLeaf) {
-        r = val[base + k];
-        mn = mx = r;
-#pragma unroll
-        for (int j = 1; j < kLeaf / 8; ++j) {
-            double v = val[base + 8 * j + k];
-            r = __dadd_rn(r, v);
-            mn = fmin(mn, v);
-            mx = fmax(mx, v);
-        }
-    } else {
-        for (int64_t e = k; e < cnt; e += 8) {   // partial unit: only min/max are used by the host
-            double v = val[base + e];
-            r = __dadd_rn(r, v);
-            mn = fmin(mn, v);
-            mx = fmax(mx, v);
-        }
-    }
-#pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-        r = __dadd_rn(r, __shfl_xor(r, off));
-        mn = fmin(mn, __shfl_xor(mn, off));
-        mx = fmax(mx, __shfl_xor(mx, off));
-    }
-    if (k == 0) {
-        usum[u] = r;
-        umin[u] = mn;
-        umax[u] = mx;
-    }
-}
-
-int launch_unit_reduce(pccm_ctx *ctx, const double *val, int64_t ns, double *unit_out, int64_t nunits)
-{
-    if (nunits <= 0) return PCCM_OK;
-    ProfScope ps(ctx, PCCM_K_REDUCE);
-    dim3 grid((unsigned)((nunits * 8 + 255) / 256));
-    hipLaunchKernelGGL(k_unit_reduce, grid, dim3(256), 0, ctx->stream, val, ns, unit_out, unit_out + nunits,
-                       unit_out + 2 * nunits, nunits);
-    PCCM_HIP(hipGetLastError());
-    return PCCM_OK;
-}
-
 // ---- batched forms: several columns per launch, results written straight into pinned host memory ------
 // A report needs up to four columns (D1/D2 x left/right).  One k_point_jobs launch evaluates all D2
 // columns, one k_unit_jobs launch reduces all columns and stores the per-unit sums/min/max and the raw
