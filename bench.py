@@ -182,14 +182,17 @@ def main():
         alg_bytes = 2.0 * (44.0 * q_rows + 32.0 * n + 4.0 * ncells)
         roofline = {"bound": "hbm", "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "traffic": None, "kernel": "grid_query (k_grid_query_coop + tail kernels)",
-                    "avg_launch_ms": round(avg_ms, 4), "launches": gq_n, "algorithmic_bytes_per_launch": alg_bytes}
+                    "traffic": None, "kernel": "grid_query (k_grid_query_coop + k_grid_finish, both directions per launch)",
+                    "avg_launch_ms": round(avg_ms, 4), "launches": gq_n, "algorithmic_bytes_per_launch": alg_bytes,
+                    "traffic_note": "PMC passes are separate rocprofv3 runs: profiles/r01/grid_1M_pmc_fetch_write.json "
+                                    "(1M: FETCH_SIZE 82.5 MB x2 by the gfx950 rule + WRITE_SIZE 136 MB per launch)",
+                    "arithmetic": "fp32 candidate filter in LDS, fp64 decisions and outputs"}
 
     line = {
         "metric": "Mpoints/s for symmetric D1+D2 PSNR, N_ref=N_deg=%s" % (f"{n // 1_000_000}M" if n % 1_000_000 == 0 else n),
         "value": round(value, 4), "unit": "Mpoints/s", "n_gpus": args.gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32 scan + f64 refine/reduce", "data": "synthetic",
+        "warmup": args.warmup, "warmup_run": max(args.warmup, 3 if not args.no_graph else 0), "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n} vs {n} uniform-random fp32 xyz + unit normals, symmetric D1+D2 MSE/PSNR + D1 Hausdorff "
                                "(BASELINE.json configs[1]+[2])",
                    "engine": args.engine, "sharding": f"query-axis x{args.gpus}", "hip_graph": not args.no_graph,

@@ -111,7 +111,6 @@ static void free_nn(NNResult &r)
     free_buf(r.flagged);
     free_buf(r.flag_thr);
     free_buf(r.tail);
-    free_buf(r.qrecs);
     if (r.idx) (void)hipFree(r.idx);
     if (r.d2) (void)hipFree(r.d2);
     r.idx = nullptr;

@@ -914,6 +914,8 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
     QueryJobs normal, selfj;
     normal.njobs = 0;
     selfj.njobs = 0;
+    int shard_dirs[3], nshard = 0, job_of_dir[3] = {-1, -1, -1};
+    int64_t shard_off[3], shard_total = 0;
     // the directions' counter pairs {rescans, tail length} live side by side: one memset covers this call's
     int dlo = 2, dhi = 0;
     for (int d = 0; d < ndirs; ++d) {
@@ -938,16 +940,13 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         if (res.begin == 0 && res.end == it.n) {
             J.qrecs = recs_all + (ii ? gr.n[0] : 0);       // whole cloud: its own cell-sorted records
         } else {
-            ProfScope ps(ctx, PCCM_K_GRID_BUILD);          // shard: sort its rows by the same cells
-            if ((rc = ensure(ctx, res.qrecs, (size_t)nq * sizeof(GridRec)))) return rc;
-            if ((rc = ensure(ctx, ctx->g_hist, (size_t)(gr.ncells + 1) * sizeof(uint32_t)))) return rc;
-            BuildJobs bj;
-            bj.njobs = 1;
-            bj.j[0] = {it.xyz64, res.begin, nq, (uint32_t *)ctx->g_hist.p};
-            bj.j[1] = bj.j[0];
-            bj.total = nq;
-            if ((rc = sort_by_cell(ctx, bj, g, (uint32_t *)ctx->g_hist.p, gr.ncells + 1, (GridRec *)res.qrecs.p))) return rc;
-            J.qrecs = (const GridRec *)res.qrecs.p;
+            // shard: its rows are sorted by the same cells into the shared shard-record buffer (below, one
+            // counting sort for all directions of this call); remember where this direction's slice starts
+            J.qrecs = nullptr;
+            shard_dirs[nshard] = dir;
+            shard_off[nshard] = shard_total;
+            shard_total += nq;
+            ++nshard;
         }
         const bool exact = it.exact32 && se.exact32;
         const double maxabs = it.maxabs > se.maxabs ? it.maxabs : se.maxabs;
@@ -965,9 +964,38 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         J.r64 = se.xyz64;
         J.nr = se.n;
         QueryJobs &dst = (dir == PCCM_DIR_SELF) ? selfj : normal;
+        job_of_dir[dir] = dst.njobs;
         dst.j[dst.njobs++] = J;
         res.stats[1] = 0;
         res.stats[2] = 0;
+    }
+    if (nshard > 0) {
+        // cell-sort the shards' rows: up to two directions per counting sort (same launches as a grid build)
+        ProfScope ps(ctx, PCCM_K_GRID_BUILD);
+        if ((rc = ensure(ctx, ctx->g_qrecs, (size_t)shard_total * sizeof(GridRec)))) return rc;
+        if ((rc = ensure(ctx, ctx->g_hist, (size_t)2 * (gr.ncells + 1) * sizeof(uint32_t)))) return rc;
+        GridRec *qbuf = (GridRec *)ctx->g_qrecs.p;
+        for (int s0 = 0; s0 < nshard; s0 += 2) {
+            const int cnt = nshard - s0 >= 2 ? 2 : 1;
+            BuildJobs bj;
+            bj.njobs = cnt;
+            bj.total = 0;
+            for (int k = 0; k < cnt; ++k) {
+                const int dir = shard_dirs[s0 + k];
+                const NNResult &res = ctx->nn[dir];
+                const Cloud &it = ctx->cloud[dir == PCCM_DIR_RIGHT ? 1 : 0];
+                bj.j[k] = {it.xyz64, res.begin, res.end - res.begin, (uint32_t *)ctx->g_hist.p + k * (gr.ncells + 1)};
+                bj.total += res.end - res.begin;
+            }
+            if (cnt == 1) bj.j[1] = bj.j[0];
+            // positions run across the jobs of one sort, i.e. they index qbuf + shard_off[s0]
+            if ((rc = sort_by_cell(ctx, bj, g, (uint32_t *)ctx->g_hist.p, (int64_t)cnt * (gr.ncells + 1), qbuf + shard_off[s0]))) return rc;
+        }
+        for (int s = 0; s < nshard; ++s) {
+            const int dir = shard_dirs[s];
+            QueryJobs &dst = (dir == PCCM_DIR_SELF) ? selfj : normal;
+            dst.j[job_of_dir[dir]].qrecs = qbuf + shard_off[s];
+        }
     }
     for (int pass = 0; pass < 2; ++pass) {
         QueryJobs &jobs = pass ? selfj : normal;
@@ -1005,7 +1033,8 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
 
 void grid_release(pccm_ctx *ctx)
 {
-    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.recs, &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum};
+    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.recs, &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum,
+                      &ctx->g_qrecs};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;

@@ -50,7 +50,7 @@ struct NNResult {
     int64_t stats[3] = {0, 0, 0};
     uint32_t *nflag_dev = nullptr;  // device counters of the last run: [0] fallback queries, [1] grid tail length
     DevBuf flagged, flag_thr;       // queries handed to the exact rescan (k2b_fallback) and their thresholds
-    DevBuf tail, qrecs;             // grid engine: unsettled ring-1 queries; cell-sorted rows of a shard
+    DevBuf tail;                    // grid engine: unsettled ring-1 queries
 };
 
 // Uniform grid over one cloud (grid engine): cells in x-fastest order, points counting-sorted by cell.
@@ -114,7 +114,7 @@ struct pccm_ctx {
     // scratch
     pccm::DevBuf part_b1, part_g, part_b2, val, stats, staging, counters;
     pccm::Grid grid;
-    pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum;   // grid-engine scratch
+    pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
     pccm::ReduceSlot slots[8];
     uint64_t nn_gen[3] = {1, 1, 1};
     // hipGraph capture of a step (pccm_graph_*): epoch changes whenever inputs, shard or any device
