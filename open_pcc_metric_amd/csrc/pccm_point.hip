@@ -22,32 +22,39 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
                                                        float *__restrict__ x32, double *__restrict__ x64,
                                                        unsigned long long *__restrict__ stats)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned long long s_mx[4], s_lo[4][3], s_hi[4][3];
+    __shared__ int s_cnt[4][3];
     unsigned long long mx = 0;
     unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};   // bounding box keys
     int inexact = 0, bad = 0, frac = 0;
-    if (i < n) {
-        double v[3];
-        float f[3];
+    // grid-stride: a bounded number of workgroups, so that the ten statistics cost a few thousand atomics on
+    // the same ten addresses (same-address atomics serialise at ~12 ns each) instead of one set per wave
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * 256) {
+        if (i < n) {
+            double v[3];
+            float f[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            v[a] = (double)src[3 * i + a];
-            f[a] = (float)v[a];
-            inexact += ((double)f[a] != v[a]) ? 1 : 0;
-            frac += (floor(v[a]) != v[a]) ? 1 : 0;
-            bad += isfinite(v[a]) ? 0 : 1;
-            unsigned long long b = (unsigned long long)__double_as_longlong(fabs(v[a]));
-            mx = b > mx ? b : mx;
-            x64[3 * i + a] = v[a];
-            lo[a] = hi[a] = order_key(v[a]);
+            for (int a = 0; a < 3; ++a) {
+                v[a] = (double)src[3 * i + a];
+                f[a] = (float)v[a];
+                inexact += ((double)f[a] != v[a]) ? 1 : 0;
+                frac += (floor(v[a]) != v[a]) ? 1 : 0;
+                bad += isfinite(v[a]) ? 0 : 1;
+                unsigned long long b = (unsigned long long)__double_as_longlong(fabs(v[a]));
+                mx = b > mx ? b : mx;
+                x64[3 * i + a] = v[a];
+                const unsigned long long key = order_key(v[a]);
+                lo[a] = key < lo[a] ? key : lo[a];
+                hi[a] = key > hi[a] ? key : hi[a];
+            }
+            float *qd = x32 + (i >> 2) * 12 + (i & 3);
+            qd[0] = f[0];
+            qd[4] = f[1];
+            qd[8] = f[2];
+        } else {
+            float *qd = x32 + (i >> 2) * 12 + (i & 3);
+            qd[0] = qd[4] = qd[8] = kPadCoord;
         }
-        float *qd = x32 + (i >> 2) * 12 + (i & 3);
-        qd[0] = f[0];
-        qd[4] = f[1];
-        qd[8] = f[2];
-    } else if (i < n_pad) {
-        float *qd = x32 + (i >> 2) * 12 + (i & 3);
-        qd[0] = qd[4] = qd[8] = kPadCoord;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -63,15 +70,32 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
             hi[a] = h > hi[a] ? h : hi[a];
         }
     }
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        if (mx) atomicMax(&stats[0], mx);
-        if (inexact) atomicAdd(&stats[1], (unsigned long long)inexact);
-        if (bad) atomicAdd(&stats[2], (unsigned long long)bad);
-        if (frac) atomicAdd(&stats[9], (unsigned long long)frac);
-#pragma unroll
+        s_mx[w] = mx;
+        s_cnt[w][0] = inexact; s_cnt[w][1] = bad; s_cnt[w][2] = frac;
+        for (int a = 0; a < 3; ++a) { s_lo[w][a] = lo[a]; s_hi[w][a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            mx = s_mx[k] > mx ? s_mx[k] : mx;
+            inexact += s_cnt[k][0]; bad += s_cnt[k][1]; frac += s_cnt[k][2];
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = s_lo[k][a] < lo[a] ? s_lo[k][a] : lo[a];
+                hi[a] = s_hi[k][a] > hi[a] ? s_hi[k][a] : hi[a];
+            }
+        }
+        // the host reads stats[1], [2] and [9] as flags and the rest as extrema, so an atomic is only issued when it
+        // would change the word: after the first few workgroups almost none are (same-address atomics serialise)
+        auto peek = [&](int k) { return __hip_atomic_load(&stats[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        if (mx > peek(0)) atomicMax(&stats[0], mx);
+        if (inexact && !peek(1)) atomicAdd(&stats[1], (unsigned long long)inexact);
+        if (bad && !peek(2)) atomicAdd(&stats[2], (unsigned long long)bad);
+        if (frac && !peek(9)) atomicAdd(&stats[9], (unsigned long long)frac);
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&stats[3 + a], lo[a]);
-            atomicMax(&stats[6 + a], hi[a]);
+            if (lo[a] < peek(3 + a)) atomicMin(&stats[3 + a], lo[a]);
+            if (hi[a] > peek(6 + a)) atomicMax(&stats[6 + a], hi[a]);
         }
     }
 }
@@ -95,7 +119,8 @@ int launch_ingest_points(pccm_ctx *ctx, const void *src, int dtype, int64_t n, i
                          double *x64, unsigned long long *stats)
 {
     ProfScope ps(ctx, PCCM_K_INGEST);
-    dim3 grid((unsigned)((n_pad + 255) / 256));
+    const int64_t blocks = (n_pad + 255) / 256;
+    dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048));
     if (dtype == PCCM_F32)
         hipLaunchKernelGGL((k_ingest_points<float>), grid, dim3(256), 0, ctx->stream, (const float *)src, n, n_pad, (float *)x32, x64, stats);
     else
