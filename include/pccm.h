@@ -158,6 +158,32 @@ int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum);
 /* Unsharded shortcut (world = 1): out = {np.sum, np.min, np.max} of the whole column in one call. */
 int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, double out[3]);
 
+/* Colours of cloud `which` ([n][3] RGB in [0, 1] as Open3D holds them; n = the cloud's point count):
+ * replaces np.asarray(cloud.colors) behind get_left/right_colors(), cloud_pair.py:114-118. */
+int pccm_set_colors(pccm_ctx *ctx, int which, const void *rgb, int64_t n, int dtype, int on_device);
+
+/* Colour metrics of one direction on the device, metric.py:302-333 and :389-427.  Per row i of the
+ * iterating cloud: own = T(rgb_own[i]), other = T(rgb_other[nn(i)]) (the gather of
+ * get_left/right_neighbour_colors(), cloud_pair.py:120-124; T = transform_colors(), metric.py:261-290,
+ * scheme 0 "rgb" | 1 "ycc" | 2 "yuv"), sq = (scale * (own - other))^2.
+ *   sum_out[c] = np.add.reduce(sq, axis=0)[c]  -- bit for bit: the left-to-right row order NumPy uses for
+ *                axis 0 (ColorMSE = sum / n, i.e. np.mean(diff**2, axis=0));
+ *   max_out[c] = np.max(sq, axis=0)[c]          (ColorHausdorffDistance; scale = 255 for "rgb", metric.py:422-425).
+ * `rows`: NULL = the neighbour rows of the context's own search of `dir` (which must cover the whole cloud);
+ * otherwise `nrows` = n_iter host rows (sharded searches: the ranks' slices gathered by the caller). */
+int pccm_color_reduce(pccm_ctx *ctx, int dir, int scheme, double scale, const int32_t *rows, int64_t nrows,
+                      double sum_out[3], double max_out[3]);
+
+/* The same rows materialised to the host, out[n_iter][3]: what = 0 own colours in the scheme,
+ * 1 neighbour colours in the scheme, 2 scale * (own - other), 3 its square. */
+int pccm_color_rows(pccm_ctx *ctx, int dir, int scheme, double scale, int what, const int32_t *rows, int64_t nrows,
+                    double *out);
+
+/* Utility behind pccm_color_reduce: out[c] = left-to-right fp64 sum of column c of three non-negative
+ * host columns cols[3][n] -- what np.add.reduce(a, axis=0) returns for the (n, 3) array a = cols.T --
+ * evaluated on the device without the dependent chain (csrc/pccm_color.hip). */
+int pccm_seq_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double out[3]);
+
 /* Host-only helper (no GPU): rows of RGB in [n][3] -> the target scheme of transform_colors(),
  * metric.py:261-290 (scheme 1 = "ycc", 2 = "yuv"), bit-compatible with the reference's per-row np.matmul. */
 int pccm_color_transform(const double *rgb, int64_t n, int scheme, double *out);

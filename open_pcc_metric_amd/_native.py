@@ -30,10 +30,14 @@ SYMBOLS = (
     "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
+    "pccm_set_colors", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum",
     "pccm_color_transform", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
 )
+
+COLOR_SCHEMES = {"rgb": 0, "ycc": 1, "yuv": 2}
+COLOR_OWN, COLOR_NEIGHBOUR, COLOR_DIFF, COLOR_SQUARE = 0, 1, 2, 3
 
 _lib = None
 
@@ -87,6 +91,10 @@ def load() -> ctypes.CDLL:
     lib.pccm_sync.argtypes = [vp]
     lib.pccm_drop_caches.argtypes = [vp]
     lib.pccm_color_transform.argtypes = [vp, i64, i32, vp]
+    lib.pccm_set_colors.argtypes = [vp, i32, vp, i64, i32, i32]
+    lib.pccm_color_reduce.argtypes = [vp, i32, i32, ctypes.c_double, vp, i64, dp, dp]
+    lib.pccm_seq_colsum.argtypes = [vp, vp, i64, dp]
+    lib.pccm_color_rows.argtypes = [vp, i32, i32, ctypes.c_double, i32, vp, i64, vp]
     lib.pccm_graph_begin.argtypes = [vp]
     lib.pccm_graph_end.argtypes = [vp, ctypes.POINTER(i32)]
     lib.pccm_graph_launch.argtypes = [vp, i32]
@@ -201,6 +209,42 @@ class Engine:
     def set_normals(self, which: int, normals) -> None:
         ptr, n, dt, dev, keep = _as_rows(normals, "normals")
         _check(self._lib.pccm_set_normals(self._ctx, int(which), ptr, n, dt, dev))
+
+    def set_colors(self, which: int, colors) -> None:
+        ptr, n, dt, dev, keep = _as_rows(colors, "colors")
+        _check(self._lib.pccm_set_colors(self._ctx, int(which), ptr, n, dt, dev))
+
+    @staticmethod
+    def _rows_arg(rows):
+        if rows is None:
+            return None, 0, None
+        keep = np.ascontiguousarray(rows, dtype=np.int32)
+        return keep.ctypes.data_as(ctypes.c_void_p), keep.shape[0], keep
+
+    def color_reduce(self, direction: int, scheme: str, scale: float = 1.0, rows=None):
+        """-> (column sums in np.add.reduce(axis=0) order, column maxima) of (scale * colour difference)**2."""
+        ptr, n, keep = self._rows_arg(rows)
+        sums, maxs = (ctypes.c_double * 3)(), (ctypes.c_double * 3)()
+        _check(self._lib.pccm_color_reduce(self._ctx, int(direction), COLOR_SCHEMES[scheme], float(scale), ptr, n, sums, maxs))
+        return np.array(sums[:], dtype=np.float64), np.array(maxs[:], dtype=np.float64)
+
+    def seq_colsum(self, columns) -> np.ndarray:
+        """np.add.reduce(a, axis=0) of a non-negative (N, 3) array, bit for bit, on the device."""
+        a = np.asarray(columns, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != 3 or a.shape[0] == 0:
+            raise ValueError("columns must have shape (N, 3), N > 0")
+        cols = np.ascontiguousarray(a.T)
+        out = (ctypes.c_double * 3)()
+        _check(self._lib.pccm_seq_colsum(self._ctx, cols.ctypes.data_as(ctypes.c_void_p), a.shape[0], out))
+        return np.array(out[:], dtype=np.float64)
+
+    def color_rows(self, direction: int, scheme: str, what: int, scale: float = 1.0, rows=None) -> np.ndarray:
+        """(n_iter, 3) rows: what = COLOR_OWN | COLOR_NEIGHBOUR | COLOR_DIFF | COLOR_SQUARE."""
+        ptr, n, keep = self._rows_arg(rows)
+        out = np.empty((self.n_iter(direction), 3), dtype=np.float64)
+        _check(self._lib.pccm_color_rows(self._ctx, int(direction), COLOR_SCHEMES[scheme], float(scale), int(what), ptr, n,
+                                         out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     def estimate_normals(self, which: int, knn: int = 30) -> None:
         """Open3D-style normals (k-NN covariance, smallest eigenvector) computed and kept on the device."""

@@ -39,7 +39,7 @@ _REDUCERS = {np.sum: "sum", np.max: "max", np.min: "min", np.amax: "max", np.ami
 
 
 def _plain(x):
-    return np.asarray(x) if isinstance(x, (DeviceColumn, DeviceRows)) else x
+    return np.asarray(x) if isinstance(x, _DeviceArray) else x
 
 
 class _DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
@@ -171,6 +171,61 @@ class DeviceRows(_DeviceArray):
         return self._pair._gather(self._dir, self._pair._engine.error_vectors(self._dir))
 
 
+class DeviceColorRows(_DeviceArray):
+    """(N, 3) colour rows of one direction, kept in HBM (metric.py:302-333, 389-427).
+
+    ``what``: ``"neighbour"`` -- colours of the matched points, ``np.take(colors, idx, axis=0)`` of
+    cloud_pair.py:120-124;  ``"diff"`` -- ``scale * (T(own) - T(neighbour))`` in ``scheme``;
+    ``"square"`` -- its square.  ``np.mean(square, axis=0)`` and ``np.max(square, axis=0)`` are answered
+    by pccm_color_reduce (bit-identical to NumPy on the materialised rows); ``255 * diff``,
+    ``diff ** 2`` and ``np.square(diff)`` stay on the device; anything else materialises."""
+    _WHAT = {"neighbour": nat.COLOR_NEIGHBOUR, "diff": nat.COLOR_DIFF, "square": nat.COLOR_SQUARE}
+
+    def __init__(self, pair: "CloudPair", direction: int, what: str, scheme: str = "rgb", scale: float = 1.0):
+        self._pair, self._dir, self._what, self._scheme, self._scale = pair, direction, what, scheme, float(scale)
+        self.shape = (pair._engine.n_iter(direction), 3)
+        self._label = f"colour {what}[dir={direction}, {scheme}, x{self._scale:g}]"
+
+    def in_scheme(self, scheme: str) -> "DeviceColorRows":
+        """own - neighbour in ``scheme`` (the np.subtract of metric.py:326-329 / 417-420)."""
+        return DeviceColorRows(self._pair, self._dir, "diff", scheme)
+
+    def _materialise(self) -> np.ndarray:
+        p = self._pair
+        return p._engine.color_rows(self._dir, self._scheme, self._WHAT[self._what], self._scale, p._colour_rows_arg(self._dir))
+
+    def _fused_ufunc(self, ufunc, method, inputs, kwargs):
+        if method != "__call__" or kwargs or self._what != "diff":
+            return NotImplemented
+        if ufunc is np.square and inputs[0] is self:
+            return DeviceColorRows(self._pair, self._dir, "square", self._scheme, self._scale)
+        if ufunc is np.power and inputs[0] is self and np.isscalar(inputs[1]) and inputs[1] == 2:
+            return DeviceColorRows(self._pair, self._dir, "square", self._scheme, self._scale)
+        if ufunc is np.multiply and len(inputs) == 2 and self._scale == 1.0:
+            other = inputs[1] if inputs[0] is self else inputs[0]
+            if np.isscalar(other) and not isinstance(other, (bool, np.bool_)):
+                return DeviceColorRows(self._pair, self._dir, "diff", self._scheme, float(other))
+        return NotImplemented
+
+    def _fused_function(self, func, args, kwargs):
+        if self._what != "square" or len(args) != 1 or args[0] is not self or set(kwargs) != {"axis"} or kwargs["axis"] != 0:
+            return NotImplemented
+        if func is np.mean:
+            sums, _ = self._pair._colour_reduction(self._dir, self._scheme, self._scale)
+            return sums / self.shape[0]                        # np.mean = np.add.reduce(axis=0) / N
+        if func in (np.max, np.amax):
+            return self._pair._colour_reduction(self._dir, self._scheme, self._scale)[1]
+        return NotImplemented
+
+
+class CloudColorsView(np.ndarray):
+    """``np.asarray(cloud.colors)`` that remembers which cloud of which pair it came from."""
+    _pccm_origin: typing.Optional[tuple] = None
+
+    def __array_finalize__(self, obj):
+        self._pccm_origin = None
+
+
 class CloudNormalsView(np.ndarray):
     """``np.asarray(cloud.normals)`` that remembers which cloud of which pair it came from, so that
     ErrorVector can keep the projection on the GPU (metric.py:92-98, 146-153)."""
@@ -197,6 +252,8 @@ class CloudPair:
         self._estimate_normals, self._normals_knn = bool(estimate_normals), int(normals_knn)
         self._estimated = [False, False]
         self._xchg, self._xchg_wanted = {}, []
+        self._colours_on_device = False
+        self._colour_red = {}
         self._graph_id = None
         self._last_wanted = None
         self._extent = None if extent is None else np.asarray(extent, dtype=np.float64)
@@ -220,6 +277,7 @@ class CloudPair:
         eng = self._engine
         self._idx_cache = {}
         self._xchg = {}
+        self._colour_red = {}
         if self._use_graph and self._last_wanted is not None and hasattr(eng, "graph_begin"):
             wants_self = "boundary" in self._last_wanted
             if self._graph_id is not None:
@@ -354,17 +412,41 @@ class CloudPair:
         view._pccm_origin = (id(self), which)
         return view
 
+    def _own_colours(self, which: int):
+        """cloud_pair.py:114-118; tagged so that the colour metrics can recognise the pair's own rows."""
+        view = np.asarray(_host_rows(self.clouds[which].colors)).view(CloudColorsView)
+        view._pccm_origin = (id(self), which)
+        return view
+
     def get_left_colors(self):
-        return self.clouds[0].colors
+        return self._own_colours(0)
 
     def get_right_colors(self):
-        return self.clouds[1].colors
+        return self._own_colours(1)
+
+    def _ensure_colours(self) -> None:
+        if not self._colours_on_device:
+            for k, cloud in enumerate(self.clouds):
+                self._engine.set_colors(k, _host_rows(cloud.colors))
+            self._colours_on_device = True
+
+    def _colour_rows_arg(self, direction: int):
+        """Neighbour rows for the colour kernels: the context's own (None) unless the search was sharded."""
+        self._ensure_colours()
+        return self._neighbour_index(direction) if self._coll.sharded else None
+
+    def _colour_reduction(self, direction: int, scheme: str, scale: float):
+        key = (direction, scheme, scale)
+        if key not in self._colour_red:
+            self._colour_red[key] = self._engine.color_reduce(direction, scheme, scale, self._colour_rows_arg(direction))
+        return self._colour_red[key]
 
     def get_left_neighbour_colors(self):
-        return np.take(_host_rows(self.clouds[1].colors), self._neighbour_index(nat.DIR_LEFT), axis=0)
+        """cloud_pair.py:120-121: the matched points' colours -- gathered on the device when asked for."""
+        return DeviceColorRows(self, nat.DIR_LEFT, "neighbour")
 
     def get_right_neighbour_colors(self):
-        return np.take(_host_rows(self.clouds[0].colors), self._neighbour_index(nat.DIR_RIGHT), axis=0)
+        return DeviceColorRows(self, nat.DIR_RIGHT, "neighbour")
 
     def prefetch_reductions(self, wanted, _remember: bool = True) -> None:
         """Enqueue the fused reductions a report is about to ask for, without waiting for any of them.

@@ -100,10 +100,12 @@ static void free_cloud(Cloud &c)
     if (c.xyz32) (void)hipFree(c.xyz32);
     if (c.xyz64) (void)hipFree(c.xyz64);
     if (c.nrm64) (void)hipFree(c.nrm64);
+    if (c.rgb64) (void)hipFree(c.rgb64);
     c.xyz32 = nullptr;
     c.xyz64 = nullptr;
     c.nrm64 = nullptr;
-    c.n = c.n_pad = c.n_nrm = 0;
+    c.rgb64 = nullptr;
+    c.n = c.n_pad = c.n_nrm = c.n_rgb = 0;
 }
 
 static void free_nn(NNResult &r)
@@ -239,7 +241,7 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
     for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
     DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->stats, &ctx->staging,
-                      &ctx->counters};
+                      &ctx->counters, &ctx->color_cols, &ctx->color_idx};
     for (DevBuf *b : bufs) free_buf(*b);
     for (auto &g : ctx->graphs) graph_free(g);
     for (auto &s : ctx->slots) {
@@ -340,6 +342,134 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
         return fail(PCCM_E_ARG, "normals of cloud %d are not finite", which);
     }
     c.n_nrm = n;
+    return PCCM_OK;
+}
+
+int pccm_set_colors(pccm_ctx *ctx, int which, const void *rgb, int64_t n, int dtype, int on_device)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
+    if (!rgb || n <= 0) return fail(PCCM_E_ARG, "empty colours");
+    if (dtype != PCCM_F32 && dtype != PCCM_F64) return fail(PCCM_E_ARG, "dtype must be PCCM_F32 or PCCM_F64");
+    Cloud &c = ctx->cloud[which];
+    if (c.n == 0) return fail(PCCM_E_STATE, "set cloud %d before its colours", which);
+    if (n != c.n) return fail(PCCM_E_ARG, "cloud %d has %lld points but %lld colours", which, (long long)c.n, (long long)n);
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    if (c.rgb64) {
+        PCCM_HIP(hipFree(c.rgb64));
+        c.rgb64 = nullptr;
+        c.n_rgb = 0;
+    }
+    PCCM_HIP(hipMalloc((void **)&c.rgb64, (size_t)n * 3 * sizeof(double)));
+    const void *dsrc = nullptr;
+    int rc = upload(ctx, rgb, (size_t)n * 3 * (dtype == PCCM_F32 ? 4 : 8), on_device, &dsrc);
+    if (rc) return rc;
+    unsigned long long *stats = (unsigned long long *)ctx->stats.p;
+    PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.rgb64, stats);      // same widening copy; non-finite values are
+    if (rc) return rc;                                                    // allowed here (NumPy propagates them)
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    c.n_rgb = n;
+    return PCCM_OK;
+}
+
+// common front end of the two colour calls: operands of direction `dir` and the neighbour rows to use
+static int color_operands(pccm_ctx *ctx, int dir, int scheme, const int32_t *rows, int64_t nrows,
+                          const Cloud **own, const Cloud **other, const int32_t **drows)
+{
+    if (dir != PCCM_DIR_LEFT && dir != PCCM_DIR_RIGHT) return fail(PCCM_E_ARG, "colour metrics exist for directions 0 and 1");
+    if (scheme < 0 || scheme > 2) return fail(PCCM_E_ARG, "unknown colour scheme %d", scheme);
+    const Cloud &it = ctx->cloud[dir == PCCM_DIR_LEFT ? 0 : 1], &se = ctx->cloud[dir == PCCM_DIR_LEFT ? 1 : 0];
+    if (!it.rgb64 || !se.rgb64) return fail(PCCM_E_STATE, "both clouds need colours (pccm_set_colors)");
+    if (rows) {
+        if (nrows != it.n) return fail(PCCM_E_ARG, "%lld neighbour rows for %lld points", (long long)nrows, (long long)it.n);
+        int rc = ensure(ctx, ctx->color_idx, (size_t)nrows * sizeof(int32_t));
+        if (rc) return rc;
+        PCCM_HIP(hipMemcpyAsync(ctx->color_idx.p, rows, (size_t)nrows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        *drows = (const int32_t *)ctx->color_idx.p;
+    } else {
+        const NNResult &res = ctx->nn[dir];
+        if (!res.valid) return fail(PCCM_E_STATE, "run pccm_nn for direction %d first", dir);
+        if (res.begin != 0 || res.end != it.n)
+            return fail(PCCM_E_STATE, "the search of direction %d was sharded: pass the gathered neighbour rows", dir);
+        *drows = res.idx;
+    }
+    *own = &it;
+    *other = &se;
+    return PCCM_OK;
+}
+
+int pccm_color_reduce(pccm_ctx *ctx, int dir, int scheme, double scale, const int32_t *rows, int64_t nrows,
+                      double sum_out[3], double max_out[3])
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (!sum_out || !max_out) return fail(PCCM_E_ARG, "null output");
+    const Cloud *own, *other;
+    const int32_t *drows;
+    int rc = color_operands(ctx, dir, scheme, rows, nrows, &own, &other, &drows);
+    if (rc) return rc;
+    const int64_t n = own->n;
+    rc = ensure(ctx, ctx->color_cols, (size_t)n * 3 * sizeof(double));
+    if (rc) return rc;
+    // stats scratch: [0..2] column maxima as bit keys, [3..5] column sums, [6] range flag
+    unsigned long long *small = (unsigned long long *)ctx->stats.p;
+    PCCM_HIP(hipMemsetAsync(small, 0, 7 * sizeof(unsigned long long), ctx->stream));
+    rc = launch_color_rows(ctx, own->rgb64, other->rgb64, drows, n, other->n, scheme, scale, 4, (double *)ctx->color_cols.p,
+                           small, (unsigned int *)(small + 6));
+    if (rc) return rc;
+    rc = launch_color_colsum(ctx, (const double *)ctx->color_cols.p, n, (double *)(small + 3));
+    if (rc) return rc;
+    unsigned long long h[7];
+    PCCM_HIP(hipMemcpyAsync(h, small, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    if (h[6]) return fail(PCCM_E_RANGE, "a neighbour row is outside the other cloud");
+    memcpy(max_out, h, 3 * sizeof(double));
+    memcpy(sum_out, h + 3, 3 * sizeof(double));
+    return PCCM_OK;
+}
+
+int pccm_seq_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double out[3])
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (!cols || !out || n <= 0) return fail(PCCM_E_ARG, "bad argument");
+    int rc = ensure(ctx, ctx->color_cols, (size_t)n * 3 * sizeof(double));
+    if (rc) return rc;
+    PCCM_HIP(hipMemcpyAsync(ctx->color_cols.p, cols, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    double *dsum = (double *)ctx->stats.p + 3;
+    rc = launch_color_colsum(ctx, (const double *)ctx->color_cols.p, n, dsum);
+    if (rc) return rc;
+    PCCM_HIP(hipMemcpyAsync(out, dsum, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    return PCCM_OK;
+}
+
+int pccm_color_rows(pccm_ctx *ctx, int dir, int scheme, double scale, int what, const int32_t *rows, int64_t nrows,
+                    double *out)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (!out) return fail(PCCM_E_ARG, "null output");
+    if (what < 0 || what > 3) return fail(PCCM_E_ARG, "what must be 0..3");
+    const Cloud *own, *other;
+    const int32_t *drows;
+    int rc = color_operands(ctx, dir, scheme, rows, nrows, &own, &other, &drows);
+    if (rc) return rc;
+    const int64_t n = own->n;
+    rc = ensure(ctx, ctx->color_cols, (size_t)n * 3 * sizeof(double));
+    if (rc) return rc;
+    unsigned long long *small = (unsigned long long *)ctx->stats.p;
+    PCCM_HIP(hipMemsetAsync(small + 6, 0, sizeof(unsigned long long), ctx->stream));
+    rc = launch_color_rows(ctx, own->rgb64, other->rgb64, drows, n, other->n, scheme, scale, what, (double *)ctx->color_cols.p,
+                           small, (unsigned int *)(small + 6));
+    if (rc) return rc;
+    unsigned long long flag = 0;
+    PCCM_HIP(hipMemcpyAsync(out, ctx->color_cols.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipMemcpyAsync(&flag, small + 6, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    if (flag) return fail(PCCM_E_RANGE, "a neighbour row is outside the other cloud");
     return PCCM_OK;
 }
 

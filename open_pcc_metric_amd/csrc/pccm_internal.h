@@ -29,6 +29,8 @@ struct Cloud {
     double *xyz64 = nullptr;    // [n][3]
     double *nrm64 = nullptr;    // [n_nrm][3]
     int64_t n_nrm = 0;
+    double *rgb64 = nullptr;    // [n_rgb][3] colours as the caller gave them (RGB in [0, 1])
+    int64_t n_rgb = 0;
     bool exact32 = true;        // every coordinate survives the fp64 -> fp32 -> fp64 round trip
     bool all_int = false;       // ... and is an integer (voxelised content: exact ties are the rule)
     double maxabs = 0.0;
@@ -113,6 +115,7 @@ struct pccm_ctx {
     pccm::NNResult nn[3];
     // scratch
     pccm::DevBuf part_b1, part_g, part_b2, val, stats, staging, counters;
+    pccm::DevBuf color_cols, color_idx;   // colour pass: squares as three columns / caller-supplied neighbour rows
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
     pccm::ReduceSlot slots[8];
@@ -203,5 +206,11 @@ int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const N
                         int normal_mode, double *out_val /*[ns]*/, double *out_err /*[ns][3] or null*/);
 
 double np_pairwise_sum(const double *a, int64_t n);
+
+// colour columns (pccm_color.hip)
+int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, const int32_t *rows, int64_t n,
+                      int64_t n_other, int scheme, double scale, int what, double *out,
+                      unsigned long long *maxkeys, unsigned int *bad);
+int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *out3);
 
 }  // namespace pccm

@@ -268,6 +268,13 @@ class _ColorPairMetric(SecondaryMetric, ColorMetric):
                 "neighbour_cloud_colors": NeighbourColors(is_left=self.is_left)}
 
     def _difference(self, origin_cloud_colors, neighbour_cloud_colors) -> np.ndarray:
+        own_rows, other_rows = origin_cloud_colors.value, neighbour_cloud_colors.value
+        pair_of = getattr(other_rows, "_pair", None)
+        if (pair_of is not None and hasattr(other_rows, "in_scheme")
+                and getattr(own_rows, "_pccm_origin", None) == (id(pair_of), 0 if self.is_left else 1)):
+            if self.color_scheme not in _PEAKS:
+                raise TypeError(f"no transform from 'rgb' to {self.color_scheme!r}")
+            return other_rows.in_scheme(self.color_scheme)      # gather, transform and subtract on the GPU
         own = transform_colors(np.copy(origin_cloud_colors.value), "rgb", self.color_scheme)
         other = transform_colors(np.copy(neighbour_cloud_colors.value), "rgb", self.color_scheme)
         return np.subtract(own, other)

@@ -65,6 +65,9 @@ def _load():
     lib.orc_point_to_plane.argtypes = [c_dp, ctypes.c_int64, c_dp, c_ip, c_dp, ctypes.c_int64,
                                        ctypes.c_int, c_dp]
     lib.orc_point_to_plane.restype = ctypes.c_int
+    lib.orc_color_columns.argtypes = [c_dp, ctypes.c_int64, c_dp, ctypes.c_int64, c_ip, ctypes.c_int, ctypes.c_double,
+                                      c_dp, c_dp, c_dp]
+    lib.orc_color_columns.restype = ctypes.c_int
     lib.orc_knn_brute.argtypes = [c_dp, ctypes.c_int64, c_dp, ctypes.c_int64, ctypes.c_int, c_ip]
     lib.orc_knn_brute.restype = ctypes.c_int
     _lib = lib
@@ -140,6 +143,37 @@ def point_to_plane(iter_pts, search_pts, nn_idx, other_normals, *, normal_index:
     if rc != 0:
         raise RuntimeError(f"oracle point_to_plane failed rc={rc}")
     return out
+
+
+COLOR_SCHEMES = {"rgb": 0, "ycc": 1, "yuv": 2}
+
+
+def color_columns(own_rgb, other_rgb, nn_idx, scheme: str, scale: float = 1.0):
+    """-> (sq, sums, maxs): ``sq = (scale * (T(own) - T(other[nn])))**2`` rows, their column sums in
+    ``np.mean(..., axis=0)``'s row order and their column maxima (metric.py:261-333, 389-427)."""
+    lib = _load()
+    a, b = _f64(own_rgb), _f64(other_rgb)
+    idx = np.ascontiguousarray(nn_idx, dtype=np.int64)
+    sq = np.empty((a.shape[0], 3), dtype=np.float64)
+    sums, maxs = np.empty(3), np.empty(3)
+    rc = lib.orc_color_columns(_dp(a), a.shape[0], _dp(b), b.shape[0], _ip(idx), COLOR_SCHEMES[scheme], float(scale),
+                               _dp(sq), _dp(sums), _dp(maxs))
+    if rc == -2:
+        raise IndexError("neighbour row outside the other cloud")
+    if rc != 0:
+        raise RuntimeError(f"oracle color_columns failed rc={rc}")
+    return sq, sums, maxs
+
+
+def color_mse(own_rgb, other_rgb, nn_idx, scheme: str) -> np.ndarray:
+    """ColorMSE.value, metric.py:302-333."""
+    _, sums, _ = color_columns(own_rgb, other_rgb, nn_idx, scheme)
+    return sums / len(own_rgb)
+
+
+def color_hausdorff(own_rgb, other_rgb, nn_idx, scheme: str) -> np.ndarray:
+    """ColorHausdorffDistance.value, metric.py:389-427 (differences scaled by 255 in "rgb")."""
+    return color_columns(own_rgb, other_rgb, nn_idx, scheme, 255.0 if scheme == "rgb" else 1.0)[2]
 
 
 def knn(points, k: int) -> np.ndarray:

@@ -272,6 +272,53 @@ int orc_point_to_plane(const double *iter_pts, int64_t n, const double *search_p
 }
 
 /* ------------------------------------------------------------------------------------
+ * Colour metrics, metric.py:261-333 and :389-427.  For row i of the iterating cloud:
+ *   own = T(rgb_own[i]), other = T(rgb_other[nn[i]])  (the np.take of cloud_pair.py:120-124),
+ *   diff = scale * (own - other)   (scale = 255 only for ColorHausdorffDistance in "rgb", :422-425),
+ *   sq[i][c] = diff * diff.
+ * T (transform_colors, :261-290) maps every row with np.matmul(M, c); with NumPy 2.2.6 / OpenBLAS on
+ * the authoring host that is fma(m2, c2, fma(m0, c0, m1 * c1)) per component -- pinned by
+ * tests/golden/fixture_eye3_color.npz and uniform_300_color.npz.  scheme: 0 rgb (identity), 1 ycc, 2 yuv.
+ * sum[c] is accumulated row by row, which is the order np.mean(sq, axis=0) uses for a C-contiguous
+ * (N, 3) array (no pairwise tree on axis 0); max[c] = np.max(sq, axis=0) (NaN propagates).
+ * Any of sq / sum / max may be NULL.
+ * ---------------------------------------------------------------------------------- */
+int orc_color_columns(const double *rgb_own, int64_t n, const double *rgb_other, int64_t n_other,
+                      const int64_t *nn, int scheme, double scale, double *sq, double *sum, double *max)
+{
+    static const double M[2][9] = {
+        {0.2126, 0.7152, 0.0722, -0.1146, -0.3854, 0.5, 0.5, -0.4542, -0.0458},
+        {0.25, 0.5, 0.25, 1, 0, -1, -0.5, 1, -0.5},
+    };
+    if (scheme < 0 || scheme > 2) return -1;
+    double s[3] = {0, 0, 0}, m[3] = {0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t j = nn[i];
+        if (j < 0 || j >= n_other) return -2;
+        const double *a = rgb_own + 3 * i, *b = rgb_other + 3 * j;
+        for (int c = 0; c < 3; ++c) {
+            double ta = a[c], tb = b[c];
+            if (scheme) {
+                const double *r = M[scheme - 1] + 3 * c;
+                ta = fma(r[2], a[2], fma(r[0], a[0], r[1] * a[1]));
+                tb = fma(r[2], b[2], fma(r[0], b[0], r[1] * b[1]));
+            }
+            double d = scale * (ta - tb);
+            double v = d * d;
+            if (sq) sq[3 * i + c] = v;
+            s[c] = i ? s[c] + v : v;
+            if (i == 0) m[c] = v;
+            else if (m[c] == m[c] && (v != v || v > m[c])) m[c] = v;      /* np.max: a NaN sticks */
+        }
+    }
+    for (int c = 0; c < 3; ++c) {
+        if (sum) sum[c] = s[c];
+        if (max) max[c] = m[c];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * Exact k nearest neighbours by brute force (self included), ascending (d2, row); used to
  * restate Open3D's estimate_normals() (cloud_pair.py:61-64; KDTreeSearchParamKNN(30)).
  * idx: [nq][k] (rows padded with -1 when nr < k).

@@ -3,7 +3,7 @@
 
 Run only in the authoring container (needs /root/reference; never on the GPU box):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case ...]
 
 What runs for real: the reference's ``open_pcc_metric.cloud_pair`` glue (cloud_pair.py:10-124),
 every metric node (metric.py), the DAG executor and result formatting (calculator.py) and
@@ -194,6 +194,14 @@ def run_case(name, spec):
             results["c" + scheme] = rows
             df = res.as_df()
             texts["c" + scheme] = {"string": df.to_string(), "csv": df.to_csv()}
+    if "ca" in spec:            # colour metrics no option reaches (metric.py:389-443) and the "yuv" scheme
+        for scheme in ("rgb", "ycc", "yuv"):
+            for is_left in (True, False):
+                side = "left" if is_left else "right"
+                for cls in (rm.ColorMSE, rm.ColorPSNR, rm.ColorHausdorffDistance, rm.ColorHausdorffDistancePSNR):
+                    MetricCalculator._calculated_metrics.clear()
+                    m = MetricCalculator(pair)._metric_recursive_calculate(cls(is_left=is_left, color_scheme=scheme))
+                    rec[f"{cls.__name__}_{side}_{scheme}"] = np.asarray(m.value, dtype=np.float64)
     # per-point D2 vectors, each direction on its own (one may raise, quirk Q1)
     for is_left in (True, False):
         side = "left" if is_left else "right"
@@ -216,8 +224,10 @@ def main():
     sys.path.insert(0, REFERENCE)
     import logging
     logging.disable(logging.CRITICAL)
+    only = set(sys.argv[1:])                     # optional: regenerate just the named cases
     for name, spec in cases().items():
-        run_case(name, spec)
+        if not only or name in only:
+            run_case(name, spec)
 
 
 if __name__ == "__main__":

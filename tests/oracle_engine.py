@@ -7,10 +7,20 @@ from open_pcc_metric_amd import _native as nat
 from oracle import oracle as orc
 
 
+def _signed_rows(rgb, _zeros, _idx, scheme):
+    """T(rgb) row by row exactly as the reference evaluates it: np.matmul(M, c) (metric.py:283-290)."""
+    if scheme == "rgb":
+        return np.array(rgb, dtype=np.float64)
+    from open_pcc_metric_amd.metric import _FROM_RGB
+    m = _FROM_RGB[scheme]
+    return np.array([np.matmul(m, c) for c in np.asarray(rgb, dtype=np.float64)]).reshape(-1, 3)
+
+
 class OracleEngine:
     def __init__(self, method="auto"):
         self.pts = [None, None]
         self.nrm = [None, None]
+        self.rgb = [None, None]
         self.rank, self.world = 0, 1
         self.res = {}
         self.method = method
@@ -26,6 +36,34 @@ class OracleEngine:
 
     def set_normals(self, which, normals):
         self.nrm[which] = np.ascontiguousarray(np.asarray(normals, dtype=np.float64))
+
+    def set_colors(self, which, colors):
+        self.rgb[which] = np.ascontiguousarray(np.asarray(colors, dtype=np.float64))
+
+    def _colour_operands(self, d, rows):
+        it, se = self._clouds(d)
+        if rows is None:
+            assert self.world == 1, "sharded search: the caller passes the gathered rows"
+            rows = self.res[d][0]
+        return self.rgb[it], self.rgb[se], np.asarray(rows, dtype=np.int64)
+
+    def color_reduce(self, d, scheme, scale=1.0, rows=None):
+        own, other, rows = self._colour_operands(d, rows)
+        _, sums, maxs = orc.color_columns(own, other, rows, scheme, scale)
+        self.calls.append(("color_reduce", d, scheme, scale))
+        return sums, maxs
+
+    def color_rows(self, d, scheme, what, scale=1.0, rows=None):
+        own, other, rows = self._colour_operands(d, rows)
+        if what == nat.COLOR_SQUARE:
+            return orc.color_columns(own, other, rows, scheme, scale)[0]
+        zeros = np.zeros((1, 3))
+        if what == nat.COLOR_OWN:         # T(own) = sqrt-free: difference against a black row, scale 1
+            return _signed_rows(own, zeros, np.zeros(len(own), np.int64), scheme)
+        if what == nat.COLOR_NEIGHBOUR:
+            return _signed_rows(other[rows], zeros, np.zeros(len(rows), np.int64), scheme)
+        return scale * (_signed_rows(own, zeros, np.zeros(len(own), np.int64), scheme)
+                        - _signed_rows(other[rows], zeros, np.zeros(len(rows), np.int64), scheme))
 
     def set_shard(self, rank, world):
         self.rank, self.world = rank, world

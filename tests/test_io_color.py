@@ -81,3 +81,56 @@ def test_color_rows_match_reference(name, scheme):
         assert same_bits(np.atleast_1d(got[tuple(key)]), np.asarray(val)), (key, got[tuple(key)], val)
     assert res.as_df().to_string() == g["meta"]["texts"]["c" + scheme]["string"]
     assert res.as_df().to_csv() == g["meta"]["texts"]["c" + scheme]["csv"]
+
+
+COLOUR_CLASSES = ("ColorMSE", "ColorPSNR", "ColorHausdorffDistance", "ColorHausdorffDistancePSNR")
+
+
+@pytest.mark.parametrize("name", ["fixture_eye3_color", "uniform_300_color"])
+@pytest.mark.parametrize("scheme", ["rgb", "ycc", "yuv"])
+def test_oracle_colour_restatement_matches_reference(name, scheme):
+    """oracle.color_mse / color_hausdorff against the reference's ColorMSE / ColorHausdorffDistance values
+    (metric.py:302-333, 389-427), both directions; pins the oracle the GPU colour path is checked with."""
+    from oracle import oracle as orc
+    g = load_golden(name)
+    for side, own, other, oc, rc in (("left", g["a"], g["b"], g["ca"], g["cb"]), ("right", g["b"], g["a"], g["cb"], g["ca"])):
+        idx, _ = orc.nn(own, other)
+        assert same_bits(orc.color_mse(oc, rc, idx, scheme), g[f"ColorMSE_{side}_{scheme}"])
+        assert same_bits(orc.color_hausdorff(oc, rc, idx, scheme), g[f"ColorHausdorffDistance_{side}_{scheme}"])
+
+
+@pytest.mark.parametrize("name", ["fixture_eye3_color", "uniform_300_color"])
+@pytest.mark.parametrize("scheme", ["rgb", "ycc", "yuv"])
+def test_every_colour_metric_through_the_dag(name, scheme):
+    """The colour metrics no CLI option reaches (ColorHausdorffDistance[PSNR], metric.py:389-443) and "yuv"."""
+    import open_pcc_metric_amd.metric as opmm
+    g = load_golden(name)
+    eng = OracleEngine()
+    pair = CloudPair(PointCloud(g["a"], g["na"], g["ca"]), PointCloud(g["b"], g["nb"], g["cb"]), extent=g["extent"], _engine=eng)
+    with np.errstate(divide="ignore"):
+        for is_left in (True, False):
+            side = "left" if is_left else "right"
+            for cls in COLOUR_CLASSES:
+                m = MetricCalculator(pair)._metric_recursive_calculate(getattr(opmm, cls)(is_left=is_left, color_scheme=scheme))
+                assert same_bits(m.value, g[f"{cls}_{side}_{scheme}"]), (cls, side, scheme)
+    assert any(c[0] == "color_reduce" for c in eng.calls)       # answered by the engine, not by host NumPy
+
+
+def test_colour_device_rows_materialise_like_numpy():
+    """Anything the fused path does not cover falls back to rows fetched from the engine: same values
+    as the reference's host expressions (np.take, transform_colors, np.subtract)."""
+    import open_pcc_metric_amd.metric as opmm
+    g = load_golden("uniform_300_color")
+    pair = CloudPair(PointCloud(g["a"], g["na"], g["ca"]), PointCloud(g["b"], g["nb"], g["cb"]), extent=g["extent"],
+                     _engine=OracleEngine())
+    idx = pair._neighbour_index(nat.DIR_LEFT)
+    neigh = pair.get_left_neighbour_colors()
+    assert np.array_equal(np.asarray(neigh), np.take(g["cb"], idx, axis=0))
+    diff = neigh.in_scheme("ycc")
+    want = opmm.transform_colors(g["ca"], "rgb", "ycc") - opmm.transform_colors(np.take(g["cb"], idx, axis=0), "rgb", "ycc")
+    assert np.array_equal(np.asarray(diff), want)
+    assert np.array_equal(np.asarray(255 * diff), 255 * want)
+    assert np.array_equal(np.asarray(diff ** 2), want ** 2)
+    assert same_bits(np.mean(diff ** 2, axis=0), np.mean(want ** 2, axis=0))
+    assert same_bits(np.max((255 * diff) ** 2, axis=0), np.max((255 * want) ** 2, axis=0))
+    assert same_bits(np.sum(diff ** 2), np.sum(want ** 2))       # not fused: materialises

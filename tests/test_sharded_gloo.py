@@ -28,13 +28,14 @@ n = int(os.environ["PCCM_N"])
 rng = np.random.default_rng(42)
 a = rng.random((n, 3), dtype=np.float32); b = rng.random((n + 37, 3), dtype=np.float32)
 na = rng.standard_normal((n, 3)); nb = rng.standard_normal((n + 37, 3))
-pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], normal_index="neighbour",
+ca = rng.integers(0, 256, (n, 3)) / 255.0; cb = rng.integers(0, 256, (n + 37, 3)) / 255.0
+pair = CloudPair(PointCloud(a, na, ca), PointCloud(b, nb, cb), extent=[1, 1, 1], normal_index="neighbour",
                  group=dist.group.WORLD, _engine=OracleEngine())
-res = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, True))).as_dict()
+res = MetricCalculator(pair).calculate(transform_options(CalculateOptions("ycc", True, True))).as_dict()
 col = np.asarray(pair.get_right_neighbour_distances())          # all-gathered column
 ev = np.asarray(pair.get_left_error_vector())
 out = {"rank": dist.get_rank(), "shard": pair._engine.shard_range(0),
-       "rows": [[list(map(str, k)), float(v).hex()] for k, v in res.items()],
+       "rows": [[list(map(str, k)), [float(x).hex() for x in np.atleast_1d(v)]] for k, v in res.items()],
        "col_sum": float(np.sum(col)).hex(), "col_len": len(col), "ev_sum": float(np.sum(ev)).hex()}
 with open(os.path.join(os.environ["PCCM_OUT"], f"rank{dist.get_rank()}.json"), "w") as fh:
     json.dump(out, fh)
@@ -71,10 +72,12 @@ def test_two_gloo_ranks_match_single_process(tmp_path, n):
     rng = np.random.default_rng(42)
     a = rng.random((n, 3), dtype=np.float32); b = rng.random((n + 37, 3), dtype=np.float32)
     na = rng.standard_normal((n, 3)); nb = rng.standard_normal((n + 37, 3))
-    pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], normal_index="neighbour",
+    ca = rng.integers(0, 256, (n, 3)) / 255.0; cb = rng.integers(0, 256, (n + 37, 3)) / 255.0
+    pair = CloudPair(PointCloud(a, na, ca), PointCloud(b, nb, cb), extent=[1, 1, 1], normal_index="neighbour",
                      _engine=OracleEngine())
-    res = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, True))).as_dict()
-    want = [[list(map(str, k)), float(v).hex()] for k, v in res.items()]
+    res = MetricCalculator(pair).calculate(transform_options(CalculateOptions("ycc", True, True))).as_dict()
+    want = [[list(map(str, k)), [float(x).hex() for x in np.atleast_1d(v)]] for k, v in res.items()]
+    assert any(k[0] == "ColorMSE" for k in res)                      # the colour rows are part of the comparison
     assert outs[0]["rows"] == want                                   # bit-identical to one process
     assert outs[0]["col_len"] == n + 37
     assert outs[0]["col_sum"] == float(np.sum(np.asarray(pair.get_right_neighbour_distances()))).hex()
