@@ -574,7 +574,16 @@ static int pick_engine(int engine)
 
 static int run_nn(pccm_ctx *ctx, int ndirs, const int *dirs, int engine)
 {
+    const bool automatic = engine == PCCM_ENGINE_AUTO && !getenv("PCCM_ENGINE");
     engine = pick_engine(engine);
+    if (automatic && ctx->cloud[0].n > 0 && ctx->cloud[1].n > 0) {
+        // distributions no uniform grid can separate (see decide_scale) go to the engine whose cost is flat
+        bool hostile = false;
+        int rc = grid_decide(ctx, &hostile);
+        if (rc) return rc;
+        if (!hostile && (rc = grid_prefers_brute(ctx, &hostile))) return rc;
+        if (hostile) engine = PCCM_ENGINE_BRUTE;
+    }
     if (engine != PCCM_ENGINE_BRUTE && engine != PCCM_ENGINE_GRID) return fail(PCCM_E_ARG, "unknown engine %d", engine);
     int todo[3], ntodo = 0, rc;
     for (int k = 0; k < ndirs; ++k) {

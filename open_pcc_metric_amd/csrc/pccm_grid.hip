@@ -453,7 +453,7 @@ constexpr int kCap = 384;         // fp32 records staged per wave (4.5 KB); more
 constexpr int kSegWidth = 61;     // + 3 bounds = 64 lanes
 constexpr float kBigF = 3.0e38f;
 
-template <bool SELF, bool TIES>
+template <bool SELF, bool TIES, bool SHIFT>
 __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeom g)
 {
     __shared__ float lx[4][kCap + 1], ly[4][kCap + 1], lz[4][kCap + 1];
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
     const bool valid = t < nq;
     const double4 qa = *reinterpret_cast<const double4 *>(&J.qrecs[valid ? t : nq - 1]);
     const double qx = qa.x, qy = qa.y, qz = qa.z;
-    const float fx = (float)qx, fy = (float)qy, fz = (float)qz;
+    float fx = (float)qx, fy = (float)qy, fz = (float)qz;
     const int qrow = rec_row(qa);
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
     const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
@@ -499,6 +499,19 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
         const int x_lo = max(xa - 1, 0);
         const int x_hi = min(xb + 2, dimx);             // index of the last bound needed
         const int my_s = (max(cx - 1, 0) - x_lo) & 63, my_e = (min(cx + 2, dimx) - x_lo) & 63;
+        // SHIFT (some input is not fp32-exact): fp32 works on coordinates relative to the segment's corner, so the
+        // rounding of the fp64 -> fp32 conversion scales with the local extent instead of the coordinate magnitude
+        // (geo-referenced clouds: |x| ~ 1e6 m at mm resolution).  The same origin is subtracted from queries and
+        // candidates, in fp64, so it cancels in exact arithmetic.
+        double ox = 0.0, oy = 0.0, oz = 0.0;
+        if (SHIFT) {
+            ox = g.org[0] + (double)x_lo * g.h[0];
+            oy = g.org[1] + (double)cyl * g.h[1];
+            oz = g.org[2] + (double)czl * g.h[2];
+            fx = (float)(qx - ox);
+            fy = (float)(qy - oy);
+            fz = (float)(qz - oz);
+        }
 
         // per run k: wave-uniform S (first record), off (start in the flattened candidate list) in
         // SGPRs; per lane only the flat start and the length of its own three-cell range
@@ -529,9 +542,9 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
                 const uint32_t bnd = off[k + 1] < W1 ? off[k + 1] : W1;
                 for (uint32_t f = a + lane; f < bnd; f += 64) {
                     const double4 r = *reinterpret_cast<const double4 *>(&srecs[S[k] + (f - off[k])]);
-                    lx[w][f - W0] = (float)r.x;
-                    ly[w][f - W0] = (float)r.y;
-                    lz[w][f - W0] = (float)r.z;
+                    lx[w][f - W0] = (float)(SHIFT ? r.x - ox : r.x);
+                    ly[w][f - W0] = (float)(SHIFT ? r.y - oy : r.y);
+                    lz[w][f - W0] = (float)(SHIFT ? r.z - oz : r.z);
                     if (SELF) lrow[w][f - W0] = rec_row(r);
                 }
             }
@@ -581,7 +594,12 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
         }
         if (inseg) {
             // certification (bound derived in pccm_brute.hip) + the ring-1 stop rule
-            const double tq = sqrt((double)best) * (1.0 + 0x1.0p-20) + J.slack32;
+            // input-rounding slack: a candidate that can win or tie in fp64 lies within d(best) of the query, so its
+            // local coordinates are bounded by the query's plus that distance; each conversion is off by at most
+            // 2^-24 of the coordinate, 2^-20 * (|q|_inf + d) covers the two points involved with room to spare
+            double slack = 0.0;
+            if (SHIFT) slack = ((double)fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) + sqrt((double)best)) * 0x1.0p-20;
+            const double tq = sqrt((double)best) * (1.0 + 0x1.0p-20) + slack;
             const double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
             bool settled = false;
             double d64 = 0.0;
@@ -755,6 +773,11 @@ static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells, d
         npts += (double)c.n;
         ++nset;
     }
+    if (ctx->grid.boxed)                 // outliers trimmed away (decide_geometry): they clamp into the boundary cells
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = ctx->grid.box_lo[a];
+            hi[a] = ctx->grid.box_hi[a];
+        }
     npts /= (nset > 0 ? nset : 1);
     double ext[3];
     int nz = 0;
@@ -800,14 +823,46 @@ static GridGeom geom_of(const Grid &gr)
     return g;
 }
 
-// occupied cells of a histogram
+// occupied cells of a histogram (out[0]) and the sum of the squared counts (out[1]: size-biased occupancy)
 __global__ __launch_bounds__(256) void k_count_occupied(const uint32_t *__restrict__ hist, int64_t m, unsigned long long *__restrict__ out)
 {
     unsigned int c = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) c += hist[i] ? 1u : 0u;
+    unsigned long long sq = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long h = hist[i];
+        c += h ? 1u : 0u;
+        sq += h * h;
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+    for (int off = 32; off > 0; off >>= 1) {
+        c += __shfl_xor(c, off);
+        sq += __shfl_xor(sq, off);
+    }
+    if ((threadIdx.x & 63) == 0 && c) {
+        atomicAdd(&out[0], (unsigned long long)c);
+        atomicAdd(&out[1], sq);
+    }
+}
+
+// per-axis histograms (kTrimBins bins over [lo, lo + kTrimBins / inv_w)) of a cloud's coordinates
+constexpr int kTrimBins = 1024;
+__global__ __launch_bounds__(256) void k_axis_hist(const double *__restrict__ x64, int64_t n, double lo0, double lo1, double lo2,
+                                                   double iw0, double iw1, double iw2, unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int s_h[3 * kTrimBins];
+    for (int k = threadIdx.x; k < 3 * kTrimBins; k += 256) s_h[k] = 0u;
+    __syncthreads();
+    const double lo[3] = {lo0, lo1, lo2}, iw[3] = {iw0, iw1, iw2};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double t = (x64[3 * i + a] - lo[a]) * iw[a];
+            t = t < 0.0 ? 0.0 : (t > (double)(kTrimBins - 1) ? (double)(kTrimBins - 1) : t);   // outside: first / last bin
+            atomicAdd(&s_h[a * kTrimBins + (int)t], 1u);
+        }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 3 * kTrimBins; k += 256)
+        if (s_h[k]) atomicAdd(&hist[k], s_h[k]);
 }
 
 // Cell edge for this pair of clouds.  The volume rule (ppc points per cell of the bounding box) is
@@ -816,6 +871,138 @@ __global__ __launch_bounds__(256) void k_count_occupied(const uint32_t *__restri
 // edge is shrunk until the OCCUPIED cells of the larger cloud hold ~2 ppc points on average (or the cell
 // budget is reached).  Costs a few histogram passes and host round trips, once per pair of clouds:
 // the result is cached and survives pccm_drop_caches().
+//
+// Hostile distributions.  A stray point far away blows the bounding box up until the cell budget leaves
+// the real data in a handful of cells, and the ring search degenerates into all-pairs inside them.  When
+// the size-biased occupancy  sb = sum(h^2) / sum(h)  (the cell population a random point sees; 2.5 for
+// uniform data, ~5 for surfaces) explodes.  So the grid covers the per-axis [0.1 %, 99.9 %] quantile box of
+// both clouds whenever that is less than half of the bounding box on some axis (coarse LDS histograms,
+// repeated while the extent keeps collapsing): cell_coord clamps, so the trimmed points live in boundary
+// cells, and face_bound already treats the grid's outer faces as infinitely far, so the search stays
+// exact.  If the size-biased occupancy is above kHeavyCell even so, and so high that
+// the ring search would evaluate more pairs per query than 1/800 of the other cloud (clumps, duplicates:
+// nothing a uniform grid can separate), the pair is marked hostile and PCCM_ENGINE_AUTO takes the
+// brute-force engine, whose scan cost does not depend on the distribution.
+constexpr double kHeavyCell = 32.0;
+
+struct Occupancy {
+    double mean = 0.0, sb = 0.0;   // points per occupied cell: plain and size-biased mean
+    int64_t ncells = 0;
+};
+
+static int measure_occupancy(pccm_ctx *ctx, const Cloud &c, double scale, Occupancy &o)
+{
+    GridGeom g;
+    int64_t ncells;
+    choose_geometry(ctx, g, ncells, scale);
+    int rc;
+    if ((rc = ensure(ctx, ctx->g_hist, (size_t)(ncells + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)c.n * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->g_rank, (size_t)c.n * sizeof(uint32_t)))) return rc;
+    uint32_t *hist = (uint32_t *)ctx->g_hist.p;
+    unsigned long long *counter = (unsigned long long *)ctx->stats.p;
+    PCCM_HIP(hipMemsetAsync(hist, 0, (size_t)(ncells + 1) * sizeof(uint32_t), ctx->stream));
+    PCCM_HIP(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    BuildJobs bj;
+    bj.njobs = 1;
+    bj.j[0] = {c.xyz64, 0, c.n, hist};
+    bj.j[1] = bj.j[0];
+    bj.total = c.n;
+    hipLaunchKernelGGL(k_grid_cells, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream, bj, g,
+                       (uint32_t *)ctx->g_cell_of.p, (uint32_t *)ctx->g_rank.p);
+    hipLaunchKernelGGL(k_count_occupied, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)hist, ncells, counter);
+    unsigned long long h[2] = {0, 0};
+    PCCM_HIP(hipMemcpyAsync(h, counter, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    o.mean = (double)c.n / (double)(h[0] ? h[0] : 1);
+    o.sb = (double)h[1] / (double)c.n;
+    o.ncells = ncells;
+    return PCCM_OK;
+}
+
+// shrink the cell edge until the occupied cells hold ~2 ppc points (or the cell budget binds)
+static int fit_scale(pccm_ctx *ctx, const Cloud &c, double &scale, Occupancy &o)
+{
+    const double target = 2.0 * points_per_cell();
+    scale = 1.0;
+    for (int it = 0; it < 4; ++it) {
+        int rc = measure_occupancy(ctx, c, scale, o);
+        if (rc) return rc;
+        if (o.mean <= 1.5 * target) break;
+        GridGeom g2;
+        int64_t nc2;
+        const double next = scale * fmax(0.35, pow(target / o.mean, 1.0 / 2.4));
+        choose_geometry(ctx, g2, nc2, next);
+        if (nc2 == o.ncells) break;                // cell budget or per-axis limit reached
+        scale = next;
+    }
+    return PCCM_OK;
+}
+
+// per-axis [eps, 1 - eps] quantile box of both clouds; returns whether it is materially smaller
+static int trim_box(pccm_ctx *ctx, bool &changed)
+{
+    Grid &gr = ctx->grid;
+    double lo[3], hi[3];
+    int64_t total = 0;
+    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int k = 0; k < 2; ++k) {
+        const Cloud &c = ctx->cloud[k];
+        if (c.n <= 0) continue;
+        total += c.n;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fmin(lo[a], c.bb_min[a]);
+            hi[a] = fmax(hi[a], c.bb_max[a]);
+        }
+    }
+    const double lo0[3] = {lo[0], lo[1], lo[2]}, hi0[3] = {hi[0], hi[1], hi[2]};
+    int rc = ensure(ctx, ctx->g_blocksum, 3 * kTrimBins * sizeof(unsigned int));
+    if (rc) return rc;
+    unsigned int *dh = (unsigned int *)ctx->g_blocksum.p;
+    std::vector<unsigned int> h(3 * kTrimBins);
+    const unsigned long long allow = (unsigned long long)((double)total * 1.0e-3);    // points given up per side and axis
+    for (int it = 0; it < 8; ++it) {
+        double iw[3];
+        for (int a = 0; a < 3; ++a) iw[a] = hi[a] > lo[a] ? (double)kTrimBins / (hi[a] - lo[a]) : 0.0;
+        PCCM_HIP(hipMemsetAsync(dh, 0, 3 * kTrimBins * sizeof(unsigned int), ctx->stream));
+        for (int k = 0; k < 2; ++k) {
+            const Cloud &c = ctx->cloud[k];
+            if (c.n <= 0) continue;
+            hipLaunchKernelGGL(k_axis_hist, dim3(512), dim3(256), 0, ctx->stream, (const double *)c.xyz64, c.n, lo[0], lo[1],
+                               lo[2], iw[0], iw[1], iw[2], dh);
+        }
+        PCCM_HIP(hipMemcpyAsync(h.data(), dh, 3 * kTrimBins * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+        bool shrunk = false;
+        for (int a = 0; a < 3; ++a) {
+            if (!(hi[a] > lo[a])) continue;
+            const unsigned int *ha = h.data() + a * kTrimBins;
+            int b0 = 0, b1 = kTrimBins - 1;
+            unsigned long long acc = 0;
+            while (b0 < b1 && acc + ha[b0] <= allow) acc += ha[b0++];
+            acc = 0;
+            while (b1 > b0 && acc + ha[b1] <= allow) acc += ha[b1--];
+            const double w = (hi[a] - lo[a]) / kTrimBins;
+            const double nlo = lo[a] + b0 * w, nhi = lo[a] + (b1 + 1) * w;
+            if ((nhi - nlo) < 0.5 * (hi[a] - lo[a])) shrunk = true;
+            lo[a] = nlo;
+            hi[a] = nhi < hi[a] ? nhi : hi[a];
+        }
+        if (!shrunk) break;
+    }
+    changed = false;
+    for (int a = 0; a < 3; ++a)
+        if ((hi[a] - lo[a]) < 0.5 * (hi0[a] - lo0[a])) changed = true;
+    if (changed) {
+        for (int a = 0; a < 3; ++a) {
+            gr.box_lo[a] = lo[a];
+            gr.box_hi[a] = hi[a];
+        }
+        gr.boxed = true;
+    }
+    return PCCM_OK;
+}
+
 static int decide_scale(pccm_ctx *ctx, uint64_t key)
 {
     Grid &gr = ctx->grid;
@@ -826,42 +1013,43 @@ static int decide_scale(pccm_ctx *ctx, uint64_t key)
     }
     const int big = ctx->cloud[1].n > ctx->cloud[0].n ? 1 : 0;
     const Cloud &c = ctx->cloud[big];
+    gr.boxed = false;
+    gr.hostile = false;
     double scale = 1.0;
-    const double target = 2.0 * points_per_cell();
-    for (int it = 0; it < 4 && c.n > 0; ++it) {
-        GridGeom g;
-        int64_t ncells;
-        choose_geometry(ctx, g, ncells, scale);
+    if (c.n > 0) {
+        Occupancy o;
         int rc;
-        if ((rc = ensure(ctx, ctx->g_hist, (size_t)(ncells + 1) * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)c.n * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(ctx, ctx->g_rank, (size_t)c.n * sizeof(uint32_t)))) return rc;
-        uint32_t *hist = (uint32_t *)ctx->g_hist.p;
-        unsigned long long *counter = (unsigned long long *)ctx->stats.p;
-        PCCM_HIP(hipMemsetAsync(hist, 0, (size_t)(ncells + 1) * sizeof(uint32_t), ctx->stream));
-        PCCM_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
-        BuildJobs bj;
-        bj.njobs = 1;
-        bj.j[0] = {c.xyz64, 0, c.n, hist};
-        bj.j[1] = bj.j[0];
-        bj.total = c.n;
-        hipLaunchKernelGGL(k_grid_cells, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream, bj, g,
-                           (uint32_t *)ctx->g_cell_of.p, (uint32_t *)ctx->g_rank.p);
-        hipLaunchKernelGGL(k_count_occupied, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)hist, ncells, counter);
-        unsigned long long occ = 0;
-        PCCM_HIP(hipMemcpyAsync(&occ, counter, sizeof(occ), hipMemcpyDeviceToHost, ctx->stream));
-        PCCM_HIP(hipStreamSynchronize(ctx->stream));
-        const double mean = (double)c.n / (double)(occ ? occ : 1);
-        if (mean <= 1.5 * target) break;
-        GridGeom g2;
-        int64_t nc2;
-        const double next = scale * fmax(0.35, pow(target / mean, 1.0 / 2.4));
-        choose_geometry(ctx, g2, nc2, next);
-        if (nc2 == ncells) break;                  // cell budget or per-axis limit reached
-        scale = next;
+        if (!getenv("PCCM_GRID_NO_TRIM")) {        // first, so that no histogram is ever built over a blown-up box
+            bool changed = false;
+            if ((rc = trim_box(ctx, changed))) return rc;
+        }
+        if ((rc = fit_scale(ctx, c, scale, o))) return rc;
+        const double n_other = (double)ctx->cloud[1 - big].n > 0 ? (double)ctx->cloud[1 - big].n : (double)c.n;
+        // integer-valued clouds (voxelised content, duplicates) are excluded: exact ties are the rule there, the grid's
+        // TIES kernel settles them in place while the brute engine would send every query to its exact rescan
+        const bool lattice = ctx->cloud[0].all_int && ctx->cloud[1].all_int;
+        gr.hostile = !lattice && o.sb > kHeavyCell && o.sb > n_other / 800.0;
+        gr.sb = o.sb;
     }
     gr.scale = scale;
     gr.scale_key = key;
+    if (getenv("PCCM_DEBUG")) {
+        GridGeom g;
+        int64_t nc;
+        choose_geometry(ctx, g, nc, scale);
+        fprintf(stderr, "[pccm] grid %d x %d x %d, scale %.3f, sb %.1f, boxed %d [%g %g %g .. %g %g %g], hostile %d\n", g.dim[0],
+                g.dim[1], g.dim[2], scale, gr.sb, (int)gr.boxed, gr.box_lo[0], gr.box_lo[1], gr.box_lo[2], gr.box_hi[0],
+                gr.box_hi[1], gr.box_hi[2], (int)gr.hostile);
+    }
+    return PCCM_OK;
+}
+
+int grid_decide(pccm_ctx *ctx, bool *hostile)
+{
+    const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
+    int rc = decide_scale(ctx, key);
+    if (rc) return rc;
+    *hostile = ctx->grid.hostile;
     return PCCM_OK;
 }
 
@@ -898,6 +1086,85 @@ static int ensure_grid(pccm_ctx *ctx)
     gr.n[0] = n0;
     gr.n[1] = n1;
     gr.key = key;
+    return PCCM_OK;
+}
+
+// Queries with no point of the searched cloud within kMaxRing cells end in an exact full rescan each
+// (wave_rescan): fine for stray points, ruinous when a whole region of one cloud has no counterpart
+// (clouds that overlap only in part, or not at all).  Counted once per pair of clouds on the freshly
+// built grid; beyond ~3 % of the queries the brute-force engine is the cheaper way to be exact.
+__global__ __launch_bounds__(256) void k_count_isolated(const GridRec *__restrict__ qrecs, int64_t nq,
+                                                        const uint32_t *__restrict__ cs, GridGeom g,
+                                                        unsigned long long *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool isolated = false;
+    if (t < nq) {
+        const double4 qa = *reinterpret_cast<const double4 *>(&qrecs[t]);
+        const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
+        const int cx = cell_coord(qa.x, g.org[0], g.inv_h[0], dimx);
+        const int cy = cell_coord(qa.y, g.org[1], g.inv_h[1], dimy);
+        const int cz = cell_coord(qa.z, g.org[2], g.inv_h[2], dimz);
+        const int x0 = max(cx - kMaxRing, 0), x1 = min(cx + kMaxRing, dimx - 1);
+        isolated = true;
+        for (int dz = 0; dz <= 2 * kMaxRing && isolated; ++dz) {
+            const int z = cz + ((dz & 1) ? (dz + 1) / 2 : -(dz / 2));          // centre row first
+            if (z < 0 || z >= dimz) continue;
+            for (int dy = 0; dy <= 2 * kMaxRing; ++dy) {
+                const int y = cy + ((dy & 1) ? (dy + 1) / 2 : -(dy / 2));
+                if (y < 0 || y >= dimy) continue;
+                const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
+                if (cs[row + x1 + 1] != cs[row + x0]) {
+                    isolated = false;
+                    break;
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(isolated);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+static int check_isolation(pccm_ctx *ctx)
+{
+    Grid &gr = ctx->grid;
+    if (gr.iso_key == gr.scale_key) return PCCM_OK;
+    if (ctx->capturing) {
+        ctx->capture_failed = true;
+        return fail(PCCM_E_STATE, "run pccm_nn once before graph capture");
+    }
+    const GridGeom g = geom_of(gr);
+    unsigned long long *counter = (unsigned long long *)ctx->stats.p;
+    PCCM_HIP(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    const GridRec *recs = (const GridRec *)gr.recs.p;
+    const uint32_t *cs = (const uint32_t *)gr.cell_start.p;
+    for (int ii = 0; ii < 2; ++ii) {                       // queries of cloud ii against the cells of the other cloud
+        const int64_t nq = gr.n[ii];
+        if (nq <= 0 || gr.n[1 - ii] <= 0) continue;
+        hipLaunchKernelGGL(k_count_isolated, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
+                           recs + (ii ? gr.n[0] : 0), nq, cs + (ii ? 0 : gr.ncells + 1), g, counter + ii);
+    }
+    unsigned long long h[2] = {0, 0};
+    PCCM_HIP(hipMemcpyAsync(h, counter, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int ii = 0; ii < 2; ++ii) gr.isolated[ii] = (int64_t)h[ii];
+    gr.iso_key = gr.scale_key;
+    if (getenv("PCCM_DEBUG")) fprintf(stderr, "[pccm] isolated queries: %lld of %lld, %lld of %lld\n", (long long)h[0],
+                                      (long long)gr.n[0], (long long)h[1], (long long)gr.n[1]);
+    return PCCM_OK;
+}
+
+// Does the built grid call for the other engine?  (PCCM_ENGINE_AUTO only; decided once per pair of clouds)
+int grid_prefers_brute(pccm_ctx *ctx, bool *yes)
+{
+    int rc;
+    *yes = false;
+    if ((rc = ensure_grid(ctx))) return rc;
+    if ((rc = check_isolation(ctx))) return rc;
+    Grid &gr = ctx->grid;
+    for (int ii = 0; ii < 2; ++ii)
+        if (gr.n[ii] > 0 && (double)gr.isolated[ii] > 0.03 * (double)gr.n[ii] && gr.isolated[ii] > 64) *yes = true;
+    if (*yes) gr.hostile = true;                           // remembered with the pair: later calls skip the grid build
     return PCCM_OK;
 }
 
@@ -1012,13 +1279,16 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         if (use_coop()) {
             dim3 grid((unsigned)((chunks + 3) / 4));
             const bool ties = ctx->cloud[0].all_int && ctx->cloud[1].all_int;
+            const bool shift = jobs.j[0].slack32 != 0.0;       // an input of this pass is not fp32-exact (never with ties)
             if (self) {
-                if (ties) hipLaunchKernelGGL((k_grid_query_coop<true, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                else hipLaunchKernelGGL((k_grid_query_coop<true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                if (ties) hipLaunchKernelGGL((k_grid_query_coop<true, true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                else if (shift) hipLaunchKernelGGL((k_grid_query_coop<true, false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                else hipLaunchKernelGGL((k_grid_query_coop<true, false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 hipLaunchKernelGGL((k_grid_finish<true>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
             } else {
-                if (ties) hipLaunchKernelGGL((k_grid_query_coop<false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                else hipLaunchKernelGGL((k_grid_query_coop<false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                if (ties) hipLaunchKernelGGL((k_grid_query_coop<false, true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                else if (shift) hipLaunchKernelGGL((k_grid_query_coop<false, false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                else hipLaunchKernelGGL((k_grid_query_coop<false, false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 hipLaunchKernelGGL((k_grid_finish<false>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
             }
         } else {

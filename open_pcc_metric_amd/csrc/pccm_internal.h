@@ -65,6 +65,12 @@ struct Grid {                    // one geometry, both clouds (grid engine)
     uint64_t key = 0;              // derived from both Cloud::version values (0 = none)
     uint64_t scale_key = 0;        // clouds the cell-edge scale below was decided for
     double scale = 1.0;            // shrink factor of the volume-rule cell edge (occupancy-adaptive)
+    bool boxed = false;            // the grid covers box_lo..box_hi (outliers trimmed) instead of the bounding box
+    double box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};
+    bool hostile = false;          // even so the cells are too crowded: PCCM_ENGINE_AUTO uses the brute engine
+    double sb = 0.0;               // size-biased points per cell the decision saw
+    uint64_t iso_key = 0;          // pair the isolation count below was taken for
+    int64_t isolated[2] = {0, 0};  // points of cloud k with nothing of the other cloud within kMaxRing cells
     int dim[3] = {1, 1, 1};
     double org[3] = {0, 0, 0};
     double h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};   // cell edge per axis
@@ -169,6 +175,8 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs);
 void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
 int grid_ensure(pccm_ctx *ctx);
+int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the current pair (cached per pair)
+int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)
 int estimate_normals(pccm_ctx *ctx, int which, int k);
 int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
 

@@ -134,3 +134,64 @@ def test_recompute_with_graph_matches_eager():
     MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, False, False)))   # a different report
     pair.recompute()
     assert MetricCalculator(pair).calculate(transform_options(opts)).as_dict() == want
+
+
+# ---- hostile distributions: automatic engine choice, trimmed grid box, local-origin fp32 ------------------------
+def _hostile(name, n):
+    u = lambda s: np.random.default_rng(s).random((n, 3), dtype=np.float32).astype(np.float64)
+    if name == "one_outlier":
+        a, b = u(1), u(2); a[0] = [1e6, 1e6, 1e6]
+    elif name == "outliers_inexact":                 # not fp32-representable: the SHIFT kernel + per-query slack
+        a, b = u(1), u(2); a[:5] *= 1e4; b[:5] *= -1e4; a += 1e-9
+    elif name == "utm_offset":                       # geo-referenced fp64 coordinates at mm noise
+        a = u(11) * 100 + np.array([5.0e5, 5.6e6, 300.0]); b = a + np.random.default_rng(12).normal(0, 0.01, a.shape)
+    elif name == "half_overlap":
+        a, b = u(15), u(16) + np.array([0.5, 0, 0])
+    elif name == "disjoint":
+        a, b = u(13), u(14) + np.array([3.0, 0, 0])
+    elif name == "gauss_clump":
+        g = np.random.default_rng(8); a, b = g.normal(0, 1, (n, 3)) ** 3, g.normal(0, 1, (n, 3)) ** 3
+    elif name == "two_clusters":
+        a, b = u(6) * 0.01, u(7) * 0.01; a[n // 2:] += 1000; b[n // 2:] += 1000
+    elif name == "heavy_tail_box":                   # 1 % of the points far outside: the box is trimmed, they clamp
+        a, b = u(20), u(21); a[: n // 100] = a[: n // 100] * 50 - 25; b[: n // 100] = b[: n // 100] * 50 - 25
+    else:
+        raise KeyError(name)
+    return a, b
+
+
+@pytest.mark.parametrize("name", ["one_outlier", "outliers_inexact", "utm_offset", "half_overlap", "disjoint", "gauss_clump",
+                                  "two_clusters", "heavy_tail_box"])
+@pytest.mark.parametrize("eng", ["auto", "grid"])
+def test_hostile_distributions_stay_exact(engine, name, eng):
+    a, b = _hostile(name, 30000)
+    engine.set_cloud(0, a)
+    engine.set_cloud(1, b)
+    engine.nn_pair(eng)
+    for d, (q, r) in enumerate(((a, b), (b, a))):
+        idx, d2 = engine.fetch_nn(d)
+        oi, od = orc.nn(q, r, method="kdtree")
+        assert np.array_equal(d2, od), (name, eng, d)
+        assert np.array_equal(idx, oi), (name, eng, d)
+    engine.nn(nat.DIR_SELF, eng)
+    idx, d2 = engine.fetch_nn(nat.DIR_SELF)
+    oi, od = orc.nn(a, a, skip_same_index=True, method="kdtree")
+    assert np.array_equal(d2, od) and np.array_equal(idx, oi), (name, eng, "self")
+
+
+def test_automatic_engine_choice(engine):
+    """PCCM_ENGINE_AUTO: the grid for ordinary pairs; the brute-force engine (stats['pairs'] = nq * nr) when the
+    clouds overlap only in part -- the decision is taken once per pair and survives pccm_drop_caches."""
+    n = 30000
+    a, b = _hostile("half_overlap", n)
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    for _ in range(2):
+        engine.drop_caches()
+        engine.nn_pair("auto")
+        assert engine.nn_stats(0)["pairs"] == n * n
+    engine.nn_pair("grid")
+    assert engine.nn_stats(0)["pairs"] == 0
+    a, b = _hostile("one_outlier", n)                 # trimmed box: stays on the grid, one exact rescan
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    engine.nn_pair("auto")
+    assert engine.nn_stats(0)["pairs"] == 0 and engine.nn_stats(0)["fallback_queries"] <= 2
