@@ -217,8 +217,10 @@ int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
         }
         ctx->own_stream = true;
     }
-    int rc = ensure(ctx, ctx->counters, 6 * sizeof(uint32_t));
+    int rc = ensure(ctx, ctx->counters, 16 * sizeof(uint32_t));      // [0..5] per-direction counters, [8..11] rescan tickets
     if (!rc) rc = ensure(ctx, ctx->stats, 10 * sizeof(unsigned long long));
+    if (!rc && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
+        rc = fail(PCCM_E_HIP, "hipMemsetAsync failed");
     if (rc) {
         pccm_ctx_destroy(ctx);
         return rc;
@@ -241,7 +243,7 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
     for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
     DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->stats, &ctx->staging,
-                      &ctx->counters, &ctx->color_cols, &ctx->color_idx};
+                      &ctx->counters, &ctx->color_cols, &ctx->color_idx, &ctx->rescan_part};
     for (DevBuf *b : bufs) free_buf(*b);
     for (auto &g : ctx->graphs) graph_free(g);
     for (auto &s : ctx->slots) {

@@ -263,55 +263,115 @@ __global__ __launch_bounds__(256) void k2_refine(const double *__restrict__ q64,
 }
 
 // ------------------------------------------------------------------------------------------
-// K2b: exact rescan of uncertified queries.  One workgroup per flagged query (grid-stride over
-// the flagged list, whose length is read on the device: no host sync between K2 and K2b).
+// K2b: exact rescan of the queries on a job's flagged list (uncertified fp32 winners of K2; queries the
+// grid engine's rings could not settle).  The list length is read on the device: no host sync before the
+// launch, and a job with an empty list costs an early exit.  Two regimes:
+//  * many flagged queries: one workgroup per query (grid-stride over the list), scanning the whole cloud;
+//  * at most kSplitMax of them (a stray point far from everything): the CLOUD is split over the workgroups
+//    instead -- every workgroup evaluates its slice against each listed query and leaves a partial
+//    (d2, row) minimum; the workgroup that takes the last ticket folds the partials.  1M points: ~0.1 ms
+//    instead of the 8 ms one wave needs to walk the cloud alone.
+// Filter and arithmetic are the same in both: candidates with d32 <= thr are evaluated in fp64 with the
+// reference's expression, lexicographic (d2, row) minimum.
 // ------------------------------------------------------------------------------------------
 template <bool SELF>
-__global__ __launch_bounds__(256) void k2b_fallback(const float *__restrict__ q32, const double *__restrict__ q64,
-                                                    int64_t q_begin, const float *__restrict__ r32,
-                                                    const double *__restrict__ r64, int64_t nr,
-                                                    const int32_t *__restrict__ flagged,
-                                                    const float *__restrict__ flag_thr,
-                                                    const uint32_t *__restrict__ nflag,
-                                                    int32_t *__restrict__ idx_out, double *__restrict__ d2_out)
+__device__ __forceinline__ void rescan_slice(const RescanJob &J, int64_t i, float thr, int64_t j0, int64_t j1, int tid,
+                                             double &bd, int &bj)
+{
+    float q_x, q_y, q_z;
+    load_pt32(J.q32, J.q_begin + i, q_x, q_y, q_z);
+    const double qx = J.q64[3 * (J.q_begin + i)], qy = J.q64[3 * (J.q_begin + i) + 1], qz = J.q64[3 * (J.q_begin + i) + 2];
+    bd = INFINITY;
+    bj = 0x7fffffff;
+    for (int64_t j = j0 + tid; j < j1; j += 256) {
+        float r_x, r_y, r_z;
+        load_pt32(J.r32, j, r_x, r_y, r_z);
+        const float d = dist32(q_x, q_y, q_z, r_x, r_y, r_z);
+        bool cand = d <= thr;
+        if (SELF) cand = cand && (j != J.q_begin + i);
+        if (cand) {
+            const double e = dist64(qx, qy, qz, J.r64[3 * j], J.r64[3 * j + 1], J.r64[3 * j + 2]);
+            if (e < bd) { bd = e; bj = (int)j; }    // j ascending per thread: first hit is the smallest
+        }
+    }
+}
+
+// lexicographic (d2, row) minimum over the workgroup; valid in thread 0
+__device__ __forceinline__ void block_lexmin(double &bd, int &bj, double *s_d, int *s_j)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const double m = wave_min_f64(bd);
+    const int cj = wave_min_i32(bd == m ? bj : 0x7fffffff);
+    __syncthreads();                                 // the previous use of s_d / s_j is over
+    if (lane == 0) { s_d[w] = m; s_j[w] = cj; }
+    __syncthreads();
+    if (tid == 0) {
+        bd = s_d[0];
+        bj = s_j[0];
+        for (int k = 1; k < 4; ++k)
+            if (s_d[k] < bd || (s_d[k] == bd && s_j[k] < bj)) { bd = s_d[k]; bj = s_j[k]; }
+    }
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void k2b_fallback(RescanJobs jobs)
 {
     __shared__ double s_d[4];
     __shared__ int s_j[4];
-    const uint32_t count = *nflag;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (uint32_t f = blockIdx.x; f < count; f += gridDim.x) {
-        const int64_t i = flagged[f];
-        const float thr = flag_thr[f];
-        float q_x, q_y, q_z;
-        load_pt32(q32, q_begin + i, q_x, q_y, q_z);
-        const double qx = q64[3 * (q_begin + i)], qy = q64[3 * (q_begin + i) + 1], qz = q64[3 * (q_begin + i) + 2];
-        double bd = INFINITY;
-        int bj = 0x7fffffff;
-        for (int64_t j = tid; j < nr; j += 256) {
-            float r_x, r_y, r_z;
-            load_pt32(r32, j, r_x, r_y, r_z);
-            const float d = dist32(q_x, q_y, q_z, r_x, r_y, r_z);
-            bool cand = d <= thr;
-            if (SELF) cand = cand && (j != q_begin + i);
-            if (cand) {
-                const double e = dist64(qx, qy, qz, r64[3 * j], r64[3 * j + 1], r64[3 * j + 2]);
-                if (e < bd) { bd = e; bj = (int)j; }    // j ascending per thread: first hit is the smallest
+    __shared__ uint32_t s_ticket;
+    const RescanJob &J = jobs.j[blockIdx.y];
+    const uint32_t count = *J.nflag;
+    if (count == 0) return;
+    const int tid = threadIdx.x;
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    if (count > (uint32_t)kSplitMax) {
+        for (uint32_t f = b; f < count; f += nb) {
+            const int64_t i = J.flagged[f];
+            double bd;
+            int bj;
+            rescan_slice<SELF>(J, i, J.flag_thr[f], 0, J.nr, tid, bd, bj);
+            block_lexmin(bd, bj, s_d, s_j);
+            if (tid == 0) {
+                J.idx_out[i] = bj;
+                J.d2_out[i] = bd;
             }
         }
-        double m = wave_min_f64(bd);
-        int cj = wave_min_i32(bd == m ? bj : 0x7fffffff);
-        if (lane == 0) { s_d[w] = m; s_j[w] = cj; }
-        __syncthreads();
-        if (tid == 0) {
-            double fm = s_d[0];
-            int fj = s_j[0];
-            for (int k = 1; k < 4; ++k)
-                if (s_d[k] < fm || (s_d[k] == fm && s_j[k] < fj)) { fm = s_d[k]; fj = s_j[k]; }
-            idx_out[i] = fj;
-            d2_out[i] = fm;
-        }
-        __syncthreads();
+        return;
     }
+    // split regime: this workgroup's slice of the searched cloud against every listed query
+    const int64_t per = (J.nr + nb - 1) / nb;
+    const int64_t j0 = (int64_t)b * per, j1 = (j0 + per < J.nr) ? j0 + per : J.nr;
+    for (uint32_t f = 0; f < count; ++f) {
+        double bd;
+        int bj;
+        rescan_slice<SELF>(J, J.flagged[f], J.flag_thr[f], j0, j1, tid, bd, bj);
+        block_lexmin(bd, bj, s_d, s_j);
+        if (tid == 0) {
+            J.part_d[(size_t)f * nb + b] = bd;
+            J.part_j[(size_t)f * nb + b] = bj;
+        }
+    }
+    __threadfence();                                 // partials visible before the ticket is taken
+    if (tid == 0) s_ticket = atomicAdd(J.ticket, 1u);
+    __syncthreads();
+    if (s_ticket != nb - 1) return;
+    __threadfence();
+    for (uint32_t f = 0; f < count; ++f) {           // last workgroup: fold the partials of every query
+        double bd = INFINITY;
+        int bj = 0x7fffffff;
+        for (uint32_t k = tid; k < nb; k += 256) {
+            const double d = __hip_atomic_load(&J.part_d[(size_t)f * nb + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int j = __hip_atomic_load(&J.part_j[(size_t)f * nb + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
+        }
+        block_lexmin(bd, bj, s_d, s_j);
+        if (tid == 0) {
+            const int64_t i = J.flagged[f];
+            J.idx_out[i] = bj;
+            J.d2_out[i] = bd;
+        }
+    }
+    if (tid == 0) *J.ticket = 0u;                    // ready for the next launch
 }
 
 // ------------------------------------------------------------------------------------------
@@ -335,20 +395,42 @@ static void launch_k1(bool self, dim3 grid, hipStream_t st, const float *q32, in
         hipLaunchKernelGGL((k1_scan<QT, false>), grid, dim3(kScanThreads), 0, st, q32, qb, nq, r32, ntiles, tps, pb1, pg, pb2);
 }
 
-// Exact rescan of the queries listed in ctx->flagged (count on the device in res.nflag_dev).
-int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res)
+// Exact rescan of the flagged queries of up to two results (counts on the device in res.nflag_dev[0]).
+int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Cloud *const *ses, NNResult *const *ress, bool self)
 {
-    const int64_t nq = res.end - res.begin;
     ProfScope ps(ctx, PCCM_K_FALLBACK);
-    dim3 grid((unsigned)(nq < 2048 ? nq : 2048));
-    if (self)
-        hipLaunchKernelGGL((k2b_fallback<true>), grid, dim3(256), 0, ctx->stream, (const float *)it.xyz32, it.xyz64, res.begin,
-                           (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)res.flagged.p, (const float *)res.flag_thr.p,
-                           res.nflag_dev, res.idx, res.d2);
-    else
-        hipLaunchKernelGGL((k2b_fallback<false>), grid, dim3(256), 0, ctx->stream, (const float *)it.xyz32, it.xyz64, res.begin,
-                           (const float *)se.xyz32, se.xyz64, se.n, (const int32_t *)res.flagged.p, (const float *)res.flag_thr.p,
-                           res.nflag_dev, res.idx, res.d2);
+    RescanJobs jobs;
+    jobs.njobs = njobs;
+    int64_t nqmax = 1;
+    const unsigned cap = 2048;
+    int rc = ensure(ctx, ctx->rescan_part, (size_t)2 * kSplitMax * cap * (sizeof(double) + sizeof(int32_t)));
+    if (rc) return rc;
+    for (int k = 0; k < njobs; ++k) {
+        const Cloud &it = *its[k], &se = *ses[k];
+        NNResult &res = *ress[k];
+        RescanJob &J = jobs.j[k];
+        J.q32 = (const float *)it.xyz32;
+        J.q64 = it.xyz64;
+        J.q_begin = res.begin;
+        J.r32 = (const float *)se.xyz32;
+        J.r64 = se.xyz64;
+        J.nr = se.n;
+        J.flagged = (const int32_t *)res.flagged.p;
+        J.flag_thr = (const float *)res.flag_thr.p;
+        J.nflag = res.nflag_dev;
+        J.idx_out = res.idx;
+        J.d2_out = res.d2;
+        J.part_d = (double *)ctx->rescan_part.p + (size_t)k * kSplitMax * cap;
+        J.part_j = (int32_t *)((double *)ctx->rescan_part.p + (size_t)2 * kSplitMax * cap) + (size_t)k * kSplitMax * cap;
+        J.ticket = (uint32_t *)ctx->counters.p + 8 + k + (self ? 2 : 0);
+        const int64_t nq = res.end - res.begin;
+        nqmax = nq > nqmax ? nq : nqmax;
+    }
+    if (njobs == 1) jobs.j[1] = jobs.j[0];
+    // enough workgroups to split a cloud finely; never more than there are queries to hand out one each
+    dim3 grid((unsigned)(nqmax < cap ? nqmax : cap), (unsigned)njobs);
+    if (self) hipLaunchKernelGGL((k2b_fallback<true>), grid, dim3(256), 0, ctx->stream, jobs);
+    else hipLaunchKernelGGL((k2b_fallback<false>), grid, dim3(256), 0, ctx->stream, jobs);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
@@ -407,7 +489,11 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
                                (float *)res.flag_thr.p, res.nflag_dev);
     }
     PCCM_HIP(hipGetLastError());
-    if ((rc = launch_fallback(ctx, it, se, self, res))) return rc;
+    {
+        const Cloud *its[1] = {&it}, *ses[1] = {&se};
+        NNResult *ress[1] = {&res};
+        if ((rc = launch_fallback(ctx, 1, its, ses, ress, self))) return rc;
+    }
     res.stats[1] = splits;
     res.stats[2] = nq * se.n;
     return PCCM_OK;

@@ -236,10 +236,9 @@ struct QueryJob {
     int32_t *idx_out;
     double *d2_out;
     GridRec *tail;              // queries ring 1 could not settle
-    uint32_t *counters;         // [0] = queries that needed the exact full rescan, [1] = tail length
-    const float *r32;           // searched cloud, fp32 quad layout (pccm_brute.hip) and fp64 rows: full rescan
-    const double *r64;
-    int64_t nr;
+    uint32_t *counters;         // [0] = queries handed to the exact full rescan (k2b_fallback), [1] = tail length
+    int32_t *flagged;           // ... their rows (relative to row_base) and fp32 filter thresholds
+    float *flag_thr;
 };
 
 struct QueryJobs {
@@ -302,42 +301,19 @@ __device__ __forceinline__ bool settled_by(double L, double d)
     return (L == INFINITY) || (L > 0.0 && d < L * L * (1.0 - 0x1.0p-30));
 }
 
-// Exact answer for ONE query by a scan of the whole searched cloud, done by the 64 lanes of the calling
-// wave together (all lanes must call it with the same, wave-uniform arguments).  Same filter as the brute
-// engine's k2b_fallback: every possible fp64 winner has d32 <= thr(best found so far), so only those are
-// evaluated in fp64; lexicographic (d2, row) minimum.  Reached by queries that kMaxRing rings could not
-// settle (isolated outliers, disjoint clouds).
-template <bool SELF>
-__device__ void wave_rescan(const QueryJob &J, double qx, double qy, double qz, int qrow, double best, Best &out)
+// A query kMaxRing rings could not settle (isolated outliers, clouds that overlap only in part) goes on the
+// result's flagged list; k2b_fallback (pccm_brute.hip), launched right after this kernel, finds its exact
+// answer by a scan of the whole searched cloud.  Same filter as there: every possible fp64 winner has
+// d32 <= thr(best found so far).
+__device__ __forceinline__ void defer_rescan(const QueryJob &J, int qrow, double best)
 {
-    const int lane = threadIdx.x & 63;
-    double tq = (best == INFINITY) ? 1.0e18 : sqrt(best) * (1.0 + 0x1.0p-20) + J.slack32;
-    double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
+    const double tq = (best == INFINITY) ? 1.0e18 : sqrt(best) * (1.0 + 0x1.0p-20) + J.slack32;
+    const double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
     float tf = thr > 3.0e38 ? 3.0e38f : (float)thr;
     tf = __uint_as_float(__float_as_uint(tf) + 1u);
-    const float fx = (float)qx, fy = (float)qy, fz = (float)qz;
-    Best b;
-    b.d = INFINITY;
-    b.idx = 0x7fffffff;
-    for (int64_t j = lane; j < J.nr; j += 64) {
-        const float *qd = J.r32 + (j >> 2) * 12 + (j & 3);
-        const float ax = fx - qd[0], ay = fy - qd[4], az = fz - qd[8];
-        float d = ax * ax;
-        d = __builtin_fmaf(ay, ay, d);
-        d = __builtin_fmaf(az, az, d);
-        if (d <= tf && !(SELF && j == qrow)) {
-            const double e = gdist64(qx, qy, qz, J.r64[3 * j], J.r64[3 * j + 1], J.r64[3 * j + 2]);
-            if (e < b.d) { b.d = e; b.idx = (int)j; }        // j ascends per lane: the first hit is the smallest row
-        }
-    }
-    double wm = b.d;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wm = fmin(wm, __shfl_xor(wm, off));
-    int wi = (b.d == wm) ? b.idx : 0x7fffffff;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wi = min(wi, __shfl_xor(wi, off));
-    out.d = wm;
-    out.idx = wi;
+    const uint32_t pos = atomicAdd(&J.counters[0], 1u);
+    J.flagged[pos] = qrow - (int)J.row_base;
+    J.flag_thr[pos] = tf;
 }
 
 // ---- per-thread ring search: the long-tail kernel (and the whole query when PCCM_GRID_COOP=0) --------------
@@ -413,21 +389,7 @@ __device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridG
                 J.idx_out[qrow - J.row_base] = b.idx;
                 J.d2_out[qrow - J.row_base] = b.d;
             }
-            // lanes still open after kMaxRing rings: the wave finishes them one at a time, all lanes scanning
-            // (the loop above keeps whole waves together: t advances by the grid size for every lane)
-            unsigned long long open = __ballot(!done);
-            while (open) {
-                const int l = __ffsll((long long)open) - 1;
-                open &= open - 1;
-                Best r;
-                wave_rescan<SELF>(J, __shfl(qx, l), __shfl(qy, l), __shfl(qz, l), __shfl(qrow, l), __shfl(b.d, l), r);
-                if ((threadIdx.x & 63) == l) {
-                    if (r.idx == 0x7fffffff) { r.idx = -1; r.d = 0.0; }
-                    J.idx_out[qrow - J.row_base] = r.idx;
-                    J.d2_out[qrow - J.row_base] = r.d;
-                    atomicAdd(&J.counters[0], 1u);
-                }
-            }
+            if (!done) defer_rescan(J, qrow, b.d);           // still open after kMaxRing rings
         }
     }
 }
@@ -707,8 +669,8 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
                 done = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, r), b.d);
             }
             if (!done) {                                     // wave-uniform
-                wave_rescan<SELF>(J, qx, qy, qz, qrow, b.d, b);
-                if (lane == 0) atomicAdd(&J.counters[0], 1u);
+                if (lane == 0) defer_rescan(J, qrow, b.d);
+                continue;
             }
             if (lane == 0) {
                 if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }
@@ -1182,6 +1144,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
     normal.njobs = 0;
     selfj.njobs = 0;
     int shard_dirs[3], nshard = 0, job_of_dir[3] = {-1, -1, -1};
+    int normal_dirs[2] = {0, 0}, self_dirs[2] = {0, 0};
     int64_t shard_off[3], shard_total = 0;
     // the directions' counter pairs {rescans, tail length} live side by side: one memset covers this call's
     int dlo = 2, dhi = 0;
@@ -1227,11 +1190,13 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         J.d2_out = res.d2;
         J.tail = (GridRec *)res.tail.p;
         J.counters = res.nflag_dev;                         // [0] full rescans, [1] tail length
-        J.r32 = (const float *)se.xyz32;
-        J.r64 = se.xyz64;
-        J.nr = se.n;
+        if ((rc = ensure(ctx, res.flagged, (size_t)nq * sizeof(int32_t)))) return rc;
+        if ((rc = ensure(ctx, res.flag_thr, (size_t)nq * sizeof(float)))) return rc;
+        J.flagged = (int32_t *)res.flagged.p;
+        J.flag_thr = (float *)res.flag_thr.p;
         QueryJobs &dst = (dir == PCCM_DIR_SELF) ? selfj : normal;
         job_of_dir[dir] = dst.njobs;
+        (dir == PCCM_DIR_SELF ? self_dirs : normal_dirs)[dst.njobs] = dir;
         dst.j[dst.njobs++] = J;
         res.stats[1] = 0;
         res.stats[2] = 0;
@@ -1297,6 +1262,19 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
             else hipLaunchKernelGGL((k_grid_query<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
         }
         PCCM_HIP(hipGetLastError());
+        {
+            // whatever the rings could not settle: exact rescan, list lengths read on the device (an empty list is an
+            // early exit)
+            const Cloud *its[2], *ses[2];
+            NNResult *ress[2];
+            const int *pd = self ? self_dirs : normal_dirs;
+            for (int k = 0; k < jobs.njobs; ++k) {
+                its[k] = &ctx->cloud[pd[k] == PCCM_DIR_RIGHT ? 1 : 0];
+                ses[k] = &ctx->cloud[pd[k] == PCCM_DIR_LEFT ? 1 : 0];
+                ress[k] = &ctx->nn[pd[k]];
+            }
+            if ((rc = launch_fallback(ctx, jobs.njobs, its, ses, ress, self))) return rc;
+        }
     }
     return PCCM_OK;
 }

@@ -121,6 +121,7 @@ struct pccm_ctx {
     pccm::NNResult nn[3];
     // scratch
     pccm::DevBuf part_b1, part_g, part_b2, val, stats, staging, counters;
+    pccm::DevBuf rescan_part;             // k2b_fallback's split regime: partial minima per (query, workgroup)
     pccm::DevBuf color_cols, color_idx;   // colour pass: squares as three columns / caller-supplied neighbour rows
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
@@ -178,7 +179,27 @@ int grid_ensure(pccm_ctx *ctx);
 int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the current pair (cached per pair)
 int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)
 int estimate_normals(pccm_ctx *ctx, int which, int k);
-int launch_fallback(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
+// exact rescan of the flagged queries of njobs <= 2 results (k2b_fallback)
+int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Cloud *const *ses, NNResult *const *ress, bool self);
+
+constexpr int kSplitMax = 32;   // flagged queries up to which the rescan splits the cloud instead of the list
+struct RescanJob {              // flagged queries of one result (k2b_fallback)
+    const float *q32, *r32;     // fp32 quad layouts of the iterating / searched cloud
+    const double *q64, *r64;
+    int64_t q_begin, nr;
+    const int32_t *flagged;     // rows relative to q_begin
+    const float *flag_thr;      // fp32 filter threshold of each
+    const uint32_t *nflag;      // list length (device)
+    int32_t *idx_out;
+    double *d2_out;
+    double *part_d;             // split regime: [kSplitMax][gridDim.x] partial minima
+    int32_t *part_j;
+    uint32_t *ticket;           // split regime: workgroups done (self-resetting)
+};
+struct RescanJobs {
+    RescanJob j[2];
+    int njobs;
+};
 
 struct PointJob {               // one D2 / PROJ column (k_point_jobs)
     const double *q64, *r64, *nrm;
