@@ -21,8 +21,8 @@
 //   query   k_grid_query_coop (ring 1, fp32 in LDS, fp64 certification; both directions)
 //           -> k_grid_finish: few unsettled queries one wave each (wave_tail), many (e.g. lattice data
 //              without the TIES kernel) one thread each (thread_search), rings 1..kMaxRing
-//           (both finish what kMaxRing rings cannot settle with a wave-cooperative exact scan of the
-//            whole searched cloud: wave_rescan)
+//           -> k2b_fallback (pccm_brute.hip): exact scan of the whole searched cloud for the queries
+//              kMaxRing rings could not settle (flagged list; its length is read on the device)
 //
 // Exactness of the stop rule.  cell(x) = clamp(floor((x - org) * inv_h)) is monotonic in x, so a
 // point in a cell left of cell c lies below org + c*h up to a few ulps of the grid's size; the
@@ -1052,7 +1052,7 @@ static int ensure_grid(pccm_ctx *ctx)
 }
 
 // Queries with no point of the searched cloud within kMaxRing cells end in an exact full rescan each
-// (wave_rescan): fine for stray points, ruinous when a whole region of one cloud has no counterpart
+// (k2b_fallback): fine for stray points, ruinous when a whole region of one cloud has no counterpart
 // (clouds that overlap only in part, or not at all).  Counted once per pair of clouds on the freshly
 // built grid; beyond ~3 % of the queries the brute-force engine is the cheaper way to be exact.
 __global__ __launch_bounds__(256) void k_count_isolated(const GridRec *__restrict__ qrecs, int64_t nq,
