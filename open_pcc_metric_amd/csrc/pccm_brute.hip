@@ -201,7 +201,7 @@ template <bool SELF>
 __global__ __launch_bounds__(256) void k2_refine(const double *__restrict__ q64, int64_t q_begin, int64_t nq,
                                                  const double *__restrict__ r64, int64_t nr,
                                                  const float *__restrict__ pb1, const int32_t *__restrict__ pg,
-                                                 const float *__restrict__ pb2, int splits, double slack,
+                                                 const float *__restrict__ pb2, int splits, double slack_scale,
                                                  int32_t *__restrict__ idx_out, double *__restrict__ d2_out,
                                                  int32_t *__restrict__ flagged, float *__restrict__ flag_thr,
                                                  uint32_t *__restrict__ nflag)
@@ -222,7 +222,12 @@ __global__ __launch_bounds__(256) void k2_refine(const double *__restrict__ q64,
         b1 = fminf(b1, p1);
         b2 = nb2;
     }
-    // every point that can win or tie in fp64 has d32 <= thr (derivation: file header)
+    // every point that can win or tie in fp64 has d32 <= thr (derivation: file header).  Inexact inputs: such a
+    // point lies within sqrt(b1) of the query, so |coordinate| <= |q|_inf + sqrt(b1) for both points involved and
+    // the fp32 conversions move the distance by less than slack_scale (2^-20) times that -- per query, so that a
+    // stray far-away point does not loosen the test for everybody
+    const double qx = q64[3 * (q_begin + ii)], qy = q64[3 * (q_begin + ii) + 1], qz = q64[3 * (q_begin + ii) + 2];
+    const double slack = slack_scale * (fmax(fmax(fabs(qx), fabs(qy)), fabs(qz)) + sqrt((double)b1));
     double tq = sqrt((double)b1) * (1.0 + 0x1.0p-20) + slack;
     double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
     const bool amb = valid && !((double)b2 > thr);
@@ -234,7 +239,6 @@ __global__ __launch_bounds__(256) void k2_refine(const double *__restrict__ q64,
         flag_thr[pos] = tf;
     }
 
-    const double qx = q64[3 * (q_begin + ii)], qy = q64[3 * (q_begin + ii) + 1], qz = q64[3 * (q_begin + ii) + 2];
     double best = 0.0;
     int bidx = -1;
     unsigned long long todo = __ballot(valid && !amb);
@@ -470,11 +474,10 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
     }
     PCCM_HIP(hipGetLastError());
 
-    // fp32 rounding of inexact inputs moves a distance by at most 2*sqrt(3)*2^-24*maxabs; 2^-20*maxabs
-    // covers it (and the fp32 arithmetic of the scan) with a wide margin.
+    // fp32 rounding of inexact inputs moves a distance by at most 2*sqrt(3)*2^-24*|coordinate|; 2^-20 times the
+    // magnitude covers it (and the fp32 arithmetic of the scan) with a wide margin (applied per query in K2)
     const bool exact = it.exact32 && se.exact32;
-    const double maxabs = it.maxabs > se.maxabs ? it.maxabs : se.maxabs;
-    const double slack = exact ? 0.0 : maxabs * 0x1.0p-20;
+    const double slack = exact ? 0.0 : 0x1.0p-20;
     {
         ProfScope ps(ctx, PCCM_K_REFINE);
         const int64_t waves = (nq + 63) / 64;
