@@ -324,9 +324,9 @@ class CloudPair:
     def _sharded_reduction(self, direction: int, metric: int):
         """(sum, min, max) of a whole column when the query axis is sharded.
 
-        The exchange vectors of ALL columns the current report asked for (prefetch_reductions) travel in
-        one all-reduce(SUM) and their extrema in one all-reduce(MAX): two collectives per report, however
-        many columns it has.  Every rank calls this with the same requests in the same order."""
+        The exchange vectors of ALL columns the current report asked for (prefetch_reductions) and their
+        extrema travel in ONE all-reduce(SUM) per report, however many columns it has.  Every rank calls
+        this with the same requests in the same order."""
         key = (direction, metric)
         if key not in self._xchg:
             eng, coll = self._engine, self._coll
@@ -337,15 +337,19 @@ class CloudPair:
             for d, m in batch:
                 xvec, mn, mx = eng.reduce(d, m, self.normal_index)
                 parts.append(xvec)
-                ext += [mx, -mn]
-            summed = coll.allreduce(np.concatenate(parts), "sum")        # x + 0 is exact: bitwise assembly
-            ext = coll.allreduce(np.asarray(ext, dtype=np.float64), "max")
+                ext += [mx, mn]
+            # the extrema ride along: every rank owns one block of slots and leaves the others zero, so the SUM
+            # hands every rank all the local extrema unchanged (x + 0 is exact) -- one collective per report
+            slots = np.zeros((coll.world, len(ext)), dtype=np.float64)
+            slots[coll.rank] = ext
+            summed = coll.allreduce(np.concatenate(parts + [slots.ravel()]), "sum")   # x + 0 is exact: bitwise assembly
+            ext = summed[len(summed) - slots.size:].reshape(slots.shape)
             pos = 0
             for i, (d, m) in enumerate(batch):
                 n = eng.n_iter(d)
                 ln = len(parts[i])
-                self._xchg[(d, m)] = (eng.finish_sum(summed[pos:pos + ln], n), np.float64(-ext[2 * i + 1]),
-                                      np.float64(ext[2 * i]))
+                self._xchg[(d, m)] = (eng.finish_sum(summed[pos:pos + ln], n), np.float64(np.min(ext[:, 2 * i + 1])),
+                                      np.float64(np.max(ext[:, 2 * i])))
                 pos += ln
         return self._xchg[key]
 

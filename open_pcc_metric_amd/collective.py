@@ -15,6 +15,8 @@ class Collective:
         self.group = group
         self.rank, self.world = 0, 1
         self._dist = None
+        self._backend = None
+        self._buffers = {}
         if enabled or group is not None:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -33,13 +35,35 @@ class Collective:
         t = torch.from_numpy(np.ascontiguousarray(arr))
         return t.cuda() if self._backend == "nccl" else t
 
+    def _staging(self, n: int, dtype):
+        """Pinned host + device buffers for the small per-report exchange (nccl): allocated once per size, so
+        a report costs two async copies and one collective instead of fresh allocations and pageable copies."""
+        import torch
+        key = (n, np.dtype(dtype).str)
+        buf = self._buffers.get(key)
+        if buf is None:
+            tdt = torch.from_numpy(np.empty(0, dtype=dtype)).dtype
+            buf = (torch.empty(n, dtype=tdt).pin_memory(), torch.empty(n, dtype=tdt, device="cuda"))
+            self._buffers[key] = buf
+        return buf
+
     def allreduce(self, arr: np.ndarray, op: str = "sum") -> np.ndarray:
         if not self.sharded:
             return arr
         dist = self._dist
+        rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+        arr = np.ascontiguousarray(arr)
+        if self._backend == "nccl" and arr.ndim == 1:
+            import torch
+            host, dev = self._staging(arr.shape[0], arr.dtype)
+            host.numpy()[:] = arr
+            dev.copy_(host, non_blocking=True)
+            dist.all_reduce(dev, op=rop, group=self.group)
+            host.copy_(dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return host.numpy().copy()
         t = self._tensor(arr)
-        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op],
-                        group=self.group)
+        dist.all_reduce(t, op=rop, group=self.group)
         return t.cpu().numpy()
 
     def allgather_rows(self, local: np.ndarray, counts) -> np.ndarray:
