@@ -17,6 +17,7 @@ N > 1   = one process per GPU (torch.distributed, backend nccl = RCCL), query ax
           GPUs) -> "scaling": "strong".
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -124,6 +125,10 @@ def main():
 
     for _ in range(max(args.warmup, 3 if not args.no_graph else 0)):   # eager, capture, first replay
         result = step()
+    # a full collection of this process (torch, pandas, ... : millions of long-lived objects) is a ~50 ms pause that
+    # would land in a random step; park what exists now in the permanent generation.  Nothing of a step is skipped.
+    gc.collect()
+    gc.freeze()
     eng.profile(args.no_graph)   # HIP events time eager launches; a hipGraph replay cannot carry them (ROCm 7.2)
     eng.profile_reset()
     fence()

@@ -67,28 +67,67 @@ class MetricCalculator:
         self._calculated_metrics[key] = metric
         return metric
 
-    def _plan(self, metrics_list: typing.List[AbstractMetric]) -> None:
-        """Walk the dependency DAG of the request (no evaluation) and let the CloudPair enqueue every
-        GPU reduction it contains; evaluation below then finds the results already on their way."""
+    def _plan(self, metrics_list: typing.List[AbstractMetric]):
+        """Resolve the dependency DAG of the request WITHOUT evaluating anything.
+
+        Returns the evaluation program: ``(metric, resolved dependencies or None)`` in exactly the order
+        and with exactly the memoisation of ``_metric_recursive_calculate`` (post-order, first object of a
+        key wins), plus the metric standing for every requested one.  Meanwhile the CloudPair is told
+        which GPU reductions the request contains (``prefetch_reductions``), so they are enqueued -- or, with
+        ``use_graph``, already running -- while this Python bookkeeping happens; the blocking part of a
+        report is then only the ``calculate()`` calls themselves."""
+        program, planned, wanted = [], {}, []
+
+        def visit(metric):
+            key = metric._key()
+            known = self._calculated_metrics.get(key) or planned.get(key)
+            if known is not None:
+                return known
+            role = getattr(metric, "_pccm_role", 0) or (1 if isinstance(metric, PrimaryMetric) else
+                                                        2 if isinstance(metric, SecondaryMetric) else 0)
+            if role == 1:
+                if isinstance(metric, BoundarySqrtDistances):
+                    wanted.append("boundary")
+                program.append((metric, None))
+            elif role == 2:
+                if isinstance(metric, EuclideanDistance):
+                    wanted.append((metric.is_left, metric.point_to_plane))
+                resolved = {name: visit(dep) for name, dep in metric._get_dependencies().items()}
+                program.append((metric, resolved))
+            else:
+                raise RuntimeError(f"Metric of unknown AbstractMetric subclass {type(metric).__name__}")
+            planned[key] = metric
+            return metric
+
+        requested = [visit(m) for m in metrics_list]
         prefetch = getattr(self._cloud_pair, "prefetch_reductions", None)
-        if prefetch is None:
-            return
-        wanted, seen, stack = [], set(), list(metrics_list)
-        while stack:
-            m = stack.pop()
-            key = m._key()
-            if key in seen or key in self._calculated_metrics:
-                continue
-            seen.add(key)
-            if isinstance(m, EuclideanDistance):
-                wanted.append((m.is_left, m.point_to_plane))
-            elif isinstance(m, BoundarySqrtDistances):
-                wanted.append("boundary")
-            if getattr(m, "_pccm_role", 0) == 2 or isinstance(m, SecondaryMetric):
-                stack.extend(m._get_dependencies().values())
-        if wanted:
-            prefetch(sorted(wanted, key=str))
+        if prefetch is not None and wanted:
+            prefetch(sorted(set(wanted), key=str))
+        return program, requested
 
     def calculate(self, metrics_list: typing.List[AbstractMetric]) -> CalculateResult:
-        self._plan(metrics_list)
-        return CalculateResult([self._metric_recursive_calculate(m) for m in metrics_list])
+        program, requested = self._plan(metrics_list)
+        pair, done = self._cloud_pair, self._calculated_metrics
+        # Two passes over the program (calculator.py:85-95, unrolled): first every node that only passes device
+        # columns along -- none of them waits for the GPU -- then, in the original order, the reducers and
+        # whatever hangs off them.  The first reducer is where the host blocks; nothing is left to do in Python
+        # after it that could have been done before.
+        late = []
+        for entry in program:
+            metric, resolved = entry
+            if getattr(metric, "_pccm_waits", False) or (resolved is not None and
+                                                          any(dep._key() not in done for dep in resolved.values())):
+                late.append(entry)
+                continue
+            if resolved is None:
+                metric.calculate(pair)
+            else:
+                metric.calculate(**resolved)
+            done[metric._key()] = metric
+        for metric, resolved in late:
+            if resolved is None:
+                metric.calculate(pair)
+            else:
+                metric.calculate(**resolved)
+            done[metric._key()] = metric
+        return CalculateResult(requested)

@@ -14,6 +14,7 @@ NumPy itself.
 from __future__ import annotations
 
 import abc
+import math
 import typing
 
 import numpy as np
@@ -118,6 +119,7 @@ class NeighbourColors(PrimaryMetric, DirectionalMetric):         # metric.py:115
 
 
 class BoundarySqrtDistances(PrimaryMetric):                      # metric.py:182-188
+    _pccm_waits = True      # reads a reduction back from the GPU: the calculator evaluates these last
     def calculate(self, cloud_pair: CloudPair) -> None:
         spacing = cloud_pair.get_boundary_sqrt_distances()
         self.value = (np.min(spacing), np.max(spacing))
@@ -193,12 +195,14 @@ class _OverEuclidean(SecondaryMetric, PointToPlaneable):
 
 
 class GeoMSE(_OverEuclidean):                                    # metric.py:213-228
+    _pccm_waits = True      # reads a reduction back from the GPU: the calculator evaluates these last
     def calculate(self, euclidean_distance: EuclideanDistance) -> None:
         column = euclidean_distance.value
         self.value = np.sum(column, axis=0) / column.shape[0]
 
 
 class GeoHausdorffDistance(_OverEuclidean):                      # metric.py:353-366 (a SQUARED distance)
+    _pccm_waits = True      # reads a reduction back from the GPU: the calculator evaluates these last
     def calculate(self, euclidean_distance: EuclideanDistance) -> None:
         self.value = np.max(euclidean_distance.value, axis=0)
 
@@ -281,12 +285,14 @@ class _ColorPairMetric(SecondaryMetric, ColorMetric):
 
 
 class ColorMSE(_ColorPairMetric):                                # metric.py:302-333
+    _pccm_waits = True      # reads a reduction back from the GPU: the calculator evaluates these last
     def calculate(self, origin_cloud_colors: CloudColors, neighbour_cloud_colors: NeighbourColors) -> None:
         diff = self._difference(origin_cloud_colors, neighbour_cloud_colors)
         self.value = np.mean(diff ** 2, axis=0)
 
 
 class ColorHausdorffDistance(_ColorPairMetric):                  # metric.py:389-427
+    _pccm_waits = True      # reads a reduction back from the GPU: the calculator evaluates these last
     def calculate(self, origin_cloud_colors: CloudColors, neighbour_cloud_colors: NeighbourColors) -> None:
         diff = self._difference(origin_cloud_colors, neighbour_cloud_colors)
         if self.color_scheme == "rgb":
@@ -334,4 +340,13 @@ class SymmetricMetric(SecondaryMetric):                          # metric.py:446
         # quality-like metrics (PSNR) report the worse = smaller side, error-like the larger;
         # the left value wins ties in both cases (Python's min/max keep the first extreme).
         pick = min if self.is_proportional else max
-        self.value = pick([lmetric.value, rmetric.value], key=np.linalg.norm)
+        self.value = pick([lmetric.value, rmetric.value], key=_norm)
+
+
+def _norm(value):
+    """np.linalg.norm(value), the reference's comparison key (metric.py:481-485).  For the scalar metrics that is
+    sqrt(x . x) = sqrt(x * x) -- evaluated here without NumPy's dispatch, same bits; arrays go to NumPy."""
+    if type(value) in (float, np.float64):
+        v = float(value)
+        return math.sqrt(v * v) if v == v else v
+    return np.linalg.norm(value)
