@@ -65,8 +65,8 @@ def cpu_baseline(a, b, na, nb):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="default: 200 (5 with --engine brute, whose step is ~0.2 s)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 5 (1 with --engine brute)")
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--engine", default="auto", choices=["auto", "brute", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -83,6 +83,10 @@ def main():
     from open_pcc_metric_amd.options import CalculateOptions, transform_options
     from open_pcc_metric_amd.point_cloud import PointCloud
 
+    if args.steps is None:
+        args.steps = 5 if args.engine == "brute" else 200
+    if args.warmup is None:
+        args.warmup = 1 if args.engine == "brute" else 5
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -185,12 +189,23 @@ def main():
         # one launch serves BOTH directions (pccm_nn_pair).  DESIGN.md section 3, per direction:
         # query record in + (idx, d2) out = 44 B/query, searched records 32 B/point, cell bounds 4 B/cell
         alg_bytes = 2.0 * (44.0 * q_rows + 32.0 * n + 4.0 * ncells)
+        # HBM bytes the kernel really moved: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes over this
+        # same command, corrected as MI355X_MICROARCH.md prescribes, committed under profiles/ (a PMC pass cannot run
+        # inside this process); only quoted for the configuration it was collected on
+        traffic, traffic_note = None, "no PMC profile committed for this engine/size"
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+                pmc = json.load(fh).get("k_grid_query_coop", {})
+            if pmc.get("points") == n and world == 1:
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_note = pmc["note"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "hbm", "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "traffic": None, "kernel": "grid_query (k_grid_query_coop + k_grid_finish, both directions per launch)",
+                    "traffic": traffic, "kernel": "k_grid_query_coop (ring-1 search of both directions in one launch)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": gq_n, "algorithmic_bytes_per_launch": alg_bytes,
-                    "traffic_note": "PMC passes are separate rocprofv3 runs: profiles/r01/grid_1M_pmc_fetch_write.json "
-                                    "(1M: FETCH_SIZE 82.5 MB x2 by the gfx950 rule + WRITE_SIZE 136 MB per launch)",
+                    "traffic_note": traffic_note,
                     "arithmetic": "fp32 candidate filter in LDS, fp64 decisions and outputs"}
 
     line = {

@@ -22,7 +22,7 @@ ENGINES = {"auto": 0, "brute": 1, "grid": 2}
 NORMAL_MODES = {"row": 0, "neighbour": 1}
 METRIC_D1, METRIC_D2, METRIC_PROJ = 0, 1, 2
 KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4, "reduce": 5,
-                  "grid_build": 6, "grid_query": 7}
+                  "grid_build": 6, "grid_query": 7, "grid_finish": 8}
 
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (

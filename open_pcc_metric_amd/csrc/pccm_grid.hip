@@ -1234,7 +1234,6 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         if (jobs.njobs == 0) continue;
         if (jobs.njobs == 1) jobs.j[1] = jobs.j[0];
         const bool self = pass == 1;
-        ProfScope ps(ctx, PCCM_K_GRID_QUERY);
         int64_t chunks = 0, nqmax = 0;
         for (int k = 0; k < jobs.njobs; ++k) {
             chunks += jobs.j[k].nchunks;
@@ -1245,19 +1244,24 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
             dim3 grid((unsigned)((chunks + 3) / 4));
             const bool ties = ctx->cloud[0].all_int && ctx->cloud[1].all_int;
             const bool shift = jobs.j[0].slack32 != 0.0;       // an input of this pass is not fp32-exact (never with ties)
-            if (self) {
-                if (ties) hipLaunchKernelGGL((k_grid_query_coop<true, true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                else if (shift) hipLaunchKernelGGL((k_grid_query_coop<true, false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                else hipLaunchKernelGGL((k_grid_query_coop<true, false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                hipLaunchKernelGGL((k_grid_finish<true>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
-            } else {
-                if (ties) hipLaunchKernelGGL((k_grid_query_coop<false, true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                else if (shift) hipLaunchKernelGGL((k_grid_query_coop<false, false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                else hipLaunchKernelGGL((k_grid_query_coop<false, false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                hipLaunchKernelGGL((k_grid_finish<false>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
+            {
+                ProfScope ps(ctx, PCCM_K_GRID_QUERY);
+                if (self) {
+                    if (ties) hipLaunchKernelGGL((k_grid_query_coop<true, true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    else if (shift) hipLaunchKernelGGL((k_grid_query_coop<true, false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    else hipLaunchKernelGGL((k_grid_query_coop<true, false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                } else {
+                    if (ties) hipLaunchKernelGGL((k_grid_query_coop<false, true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    else if (shift) hipLaunchKernelGGL((k_grid_query_coop<false, false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    else hipLaunchKernelGGL((k_grid_query_coop<false, false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                }
             }
+            ProfScope pf(ctx, PCCM_K_GRID_FINISH);
+            if (self) hipLaunchKernelGGL((k_grid_finish<true>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
+            else hipLaunchKernelGGL((k_grid_finish<false>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
         } else {
             dim3 grid((unsigned)((nqmax + 255) / 256));
+            ProfScope ps(ctx, PCCM_K_GRID_QUERY);
             if (self) hipLaunchKernelGGL((k_grid_query<true>), grid, dim3(256), 0, ctx->stream, jobs, g);
             else hipLaunchKernelGGL((k_grid_query<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
         }
