@@ -195,3 +195,23 @@ def test_automatic_engine_choice(engine):
     engine.set_cloud(0, a); engine.set_cloud(1, b)
     engine.nn_pair("auto")
     assert engine.nn_stats(0)["pairs"] == 0 and engine.nn_stats(0)["fallback_queries"] <= 2
+
+
+def test_graph_replay_on_a_pair_that_takes_the_brute_engine():
+    """use_graph with a partly overlapping pair (automatic choice: brute force): every recompute() -- eager, captured,
+    replayed -- must give the oracle's report."""
+    from oracle.oracle import OraclePair
+    n = 20000
+    a, b = _hostile("half_overlap", n)
+    rng = np.random.default_rng(5)
+    na = rng.standard_normal((n, 3)); nb = rng.standard_normal((n, 3))
+    opts = transform_options(CalculateOptions(None, True, True))
+    want = OraclePair(a, b, na, nb).report(hausdorff=True, point_to_plane_=True, peak=1.0)
+    pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], use_graph=True)
+    assert pair._engine.nn_stats(0)["pairs"] == n * n            # the brute engine ran
+    for _ in range(4):
+        got = MetricCalculator(pair).calculate(opts).as_dict()
+        assert list(got) == list(want)
+        for k in want:
+            assert np.array_equal(np.float64(got[k]), np.float64(want[k])), k
+        pair.recompute()
