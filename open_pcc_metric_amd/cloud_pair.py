@@ -262,6 +262,7 @@ class CloudPair:
             if device is None:
                 device = int(os.environ.get("LOCAL_RANK", "0")) if self._coll.sharded else 0
             _engine = nat.Engine(device)          # raises without libpccm.so or without a GPU
+            self._coll.device = device            # the nccl exchange is staged on the same GPU
         self._engine = _engine
         for k, cloud in enumerate(self.clouds):
             _engine.set_cloud(k, cloud.points)

@@ -7,12 +7,15 @@ columns are all-gathered only when a getter materialises them.
 """
 from __future__ import annotations
 
+import typing
+
 import numpy as np
 
 
 class Collective:
-    def __init__(self, group=None, enabled: bool = False):
+    def __init__(self, group=None, enabled: bool = False, device: typing.Optional[int] = None):
         self.group = group
+        self.device = device        # GPU whose memory stages the nccl exchange (None: torch's current device)
         self.rank, self.world = 0, 1
         self._dist = None
         self._backend = None
@@ -33,7 +36,11 @@ class Collective:
     def _tensor(self, arr: np.ndarray):
         import torch
         t = torch.from_numpy(np.ascontiguousarray(arr))
-        return t.cuda() if self._backend == "nccl" else t
+        return t.to(self._cuda()) if self._backend == "nccl" else t
+
+    def _cuda(self):
+        import torch
+        return torch.device("cuda", self.device if self.device is not None else torch.cuda.current_device())
 
     def _staging(self, n: int, dtype):
         """Pinned host + device buffers for the small per-report exchange (nccl): allocated once per size, so
@@ -43,7 +50,7 @@ class Collective:
         buf = self._buffers.get(key)
         if buf is None:
             tdt = torch.from_numpy(np.empty(0, dtype=dtype)).dtype
-            buf = (torch.empty(n, dtype=tdt).pin_memory(), torch.empty(n, dtype=tdt, device="cuda"))
+            buf = (torch.empty(n, dtype=tdt).pin_memory(), torch.empty(n, dtype=tdt, device=self._cuda()))
             self._buffers[key] = buf
         return buf
 
@@ -60,7 +67,7 @@ class Collective:
             dev.copy_(host, non_blocking=True)
             dist.all_reduce(dev, op=rop, group=self.group)
             host.copy_(dev, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self._cuda()).synchronize()
             return host.numpy().copy()
         t = self._tensor(arr)
         dist.all_reduce(t, op=rop, group=self.group)
