@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from typing import Optional, Tuple
 
 import numpy as np
@@ -57,10 +58,13 @@ def load() -> ctypes.CDLL:
             "Run `make -C open_pcc_metric_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
     # PyTorch ships its own libamdhip64.so.7; loading it first makes libpccm.so bind to that same
     # runtime (one HIP runtime per process), so torch device tensors and streams can be handed in.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # PCCM_NO_TORCH=1 (the command line sets it for single-process runs): skip the ~1.5 s import; nothing in this
+    # process may import torch afterwards and expect to see the GPU.
+    if "torch" in sys.modules or os.environ.get("PCCM_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     dp = ctypes.POINTER(ctypes.c_double)
