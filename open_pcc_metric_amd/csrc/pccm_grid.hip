@@ -18,9 +18,12 @@
 // Launch structure (everything that exists per direction or per cloud is fused into one launch over
 // "jobs", because at these sizes the kernels are latency-bound and launches cost ~5 us each):
 //   build   k_grid_cells (cell id + rank by atomicAdd, both clouds) -> exclusive scan -> k_grid_scatter
-//   query   k_grid_query_coop (ring 1, fp32 in LDS, fp64 certification; both directions)
-//           -> k_grid_finish: few unsettled queries one wave each (wave_tail), many (e.g. lattice data
-//              without the TIES kernel) one thread each (thread_search), rings 1..kMaxRing
+//   query   well-filled x-rows (volumetric float data):
+//             k_grid_query_coop (ring 1, fp32 in LDS, fp64 certification; both directions)
+//             -> k_grid_finish: few unsettled queries one wave each (wave_tail), many one thread each
+//                (thread_search), rings 1..kMaxRing
+//           surfaces and integer lattices (decide_scale, use_coop):
+//             k_grid_query = thread_search for every query, fp64 throughout
 //           -> k2b_fallback (pccm_brute.hip): exact scan of the whole searched cloud for the queries
 //              kMaxRing rings could not settle (flagged list; its length is read on the device)
 //
@@ -408,14 +411,12 @@ __device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridG
 //   4. certifies like k2_refine: if the second-best d32 is above thr(best d32) the fp32 winner is the
 //      unique fp64 winner, whose exact d2 is then computed once from its fp64 record.
 // Queries that cannot be certified (near ties) or whose ring-1 result does not satisfy the stop rule go
-// to `tail`.  TIES: instantiation for voxelised content (integer coordinates, where exact ties are the
-// rule): uncertified queries are settled in place with fp64 arithmetic over the staged candidates.  It
-// needs more registers, so it is only used when the ingest saw integer-valued, fp32-exact clouds.
+// to `tail`.  Integer-valued clouds, where exact ties are the rule, never come here (use_coop).
 constexpr int kCap = 384;         // fp32 records staged per wave (4.5 KB); more -> several windows
 constexpr int kSegWidth = 61;     // + 3 bounds = 64 lanes
 constexpr float kBigF = 3.0e38f;
 
-template <bool SELF, bool TIES, bool SHIFT>
+template <bool SELF, bool SHIFT>
 __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeom g)
 {
     __shared__ float lx[4][kCap + 1], ly[4][kCap + 1], lz[4][kCap + 1];
@@ -571,39 +572,6 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
                 d64 = gdist64(qx, qy, qz, r.x, r.y, r.z);
                 wrow = rec_row(r);
                 settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
-            } else if (TIES && bestpos != 0xffffffffu && J.slack32 == 0.0 && T <= (uint32_t)kCap) {
-                // Near or exact tie (the rule on voxelised content).  Both clouds are fp32-exact, so the
-                // staged fp32 coordinates ARE the fp64 coordinates: settle the tie right here with the
-                // reference's fp64 arithmetic over the candidates within the band, smallest row first.
-                float tf = (float)thr;
-                tf = __uint_as_float(__float_as_uint(tf) + 1u);
-                Best b;
-                b.d = INFINITY;
-                b.idx = 0x7fffffff;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    for (uint32_t f = rs[k]; f < rs[k] + rl[k]; ++f) {
-                        const float x = lx[w][f], y = ly[w][f], z = lz[w][f];
-                        const float ax = fx - x, ay = fy - y, az = fz - z;
-                        float d = ax * ax;
-                        d = __builtin_fmaf(ay, ay, d);
-                        d = __builtin_fmaf(az, az, d);
-                        if (d <= tf) {
-                            // rows are not staged for plain directions: fetch the few that matter
-                            const int row = SELF ? lrow[w][f] : srecs[f + (S[k] - off[k])].idx;
-                            if (SELF && row == qrow) continue;
-                            const double e = gdist64(qx, qy, qz, (double)x, (double)y, (double)z);
-                            const bool better = e < b.d || (e == b.d && row < b.idx);
-                            b.d = better ? e : b.d;
-                            b.idx = better ? row : b.idx;
-                        }
-                    }
-                }
-                if (b.idx != 0x7fffffff) {
-                    d64 = b.d;
-                    wrow = b.idx;
-                    settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
-                }
             }
             if (settled) {
                 J.idx_out[qrow - J.row_base] = wrow;
@@ -708,13 +676,28 @@ static double points_per_cell()
     return k;
 }
 
-static bool use_coop()
+// Which query kernel?  (PCCM_GRID_COOP=0/1 forces one; default: decided per pair of clouds in decide_scale)
+// The cooperative kernel amortises its per-segment work (bounds, staging) over the queries of a wave that share an
+// x-row of cells; that pays when rows are well filled -- volumetric float data (1.5x over the per-thread kernel) and
+// crowded cells (LiDAR: 2x) -- and backfires when they are not: on surfaces a row holds a handful of points, a wave
+// walks a dozen segments with a few lanes active in each (sphere surface, 1M points: 0.83 ms vs 0.28 ms per-thread;
+// voxelised: 1.55 vs 0.33 ms), and on integer lattices its in-place tie resolution is no match for plain fp64
+// (128^3 lattice volume: 4.4 vs 0.22 ms).  Measured crossover for float data: ~40 points per x-row of the grid.
+constexpr double kCoopMinPointsPerRow = 40.0;
+
+static int coop_override()
 {
-    static bool on = [] {
+    static int v = [] {
         const char *e = getenv("PCCM_GRID_COOP");
-        return !(e && e[0] == '0');
+        return e ? (e[0] == '0' ? 0 : 1) : -1;
     }();
-    return on;
+    return v;
+}
+
+static bool use_coop(const pccm_ctx *ctx)
+{
+    const int o = coop_override();
+    return o >= 0 ? o == 1 : ctx->grid.coop;
 }
 
 // One geometry for BOTH clouds (union bounding box, cell edge from the mean point count): a query's
@@ -988,10 +971,14 @@ static int decide_scale(pccm_ctx *ctx, uint64_t key)
         if ((rc = fit_scale(ctx, c, scale, o))) return rc;
         const double n_other = (double)ctx->cloud[1 - big].n > 0 ? (double)ctx->cloud[1 - big].n : (double)c.n;
         // integer-valued clouds (voxelised content, duplicates) are excluded: exact ties are the rule there, the grid's
-        // TIES kernel settles them in place while the brute engine would send every query to its exact rescan
+        // per-thread fp64 search handles them directly while the brute engine would send every query to its exact rescan
         const bool lattice = ctx->cloud[0].all_int && ctx->cloud[1].all_int;
         gr.hostile = !lattice && o.sb > kHeavyCell && o.sb > n_other / 800.0;
         gr.sb = o.sb;
+        GridGeom gg;
+        int64_t nc;
+        choose_geometry(ctx, gg, nc, scale);
+        gr.coop = !lattice && (double)c.n / ((double)gg.dim[1] * (double)gg.dim[2]) >= kCoopMinPointsPerRow;
     }
     gr.scale = scale;
     gr.scale_key = key;
@@ -999,9 +986,9 @@ static int decide_scale(pccm_ctx *ctx, uint64_t key)
         GridGeom g;
         int64_t nc;
         choose_geometry(ctx, g, nc, scale);
-        fprintf(stderr, "[pccm] grid %d x %d x %d, scale %.3f, sb %.1f, boxed %d [%g %g %g .. %g %g %g], hostile %d\n", g.dim[0],
-                g.dim[1], g.dim[2], scale, gr.sb, (int)gr.boxed, gr.box_lo[0], gr.box_lo[1], gr.box_lo[2], gr.box_hi[0],
-                gr.box_hi[1], gr.box_hi[2], (int)gr.hostile);
+        fprintf(stderr, "[pccm] grid %d x %d x %d, scale %.3f, sb %.1f, boxed %d [%g %g %g .. %g %g %g], hostile %d, kernel %s\n",
+                g.dim[0], g.dim[1], g.dim[2], scale, gr.sb, (int)gr.boxed, gr.box_lo[0], gr.box_lo[1], gr.box_lo[2], gr.box_hi[0],
+                gr.box_hi[1], gr.box_hi[2], (int)gr.hostile, gr.coop ? "cooperative" : "per-thread");
     }
     return PCCM_OK;
 }
@@ -1240,20 +1227,17 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
             nqmax = jobs.j[k].nq > nqmax ? jobs.j[k].nq : nqmax;
         }
         dim3 tgrid((unsigned)((nqmax + 255) / 256));     // long tails need the whole grid; idle blocks just exit
-        if (use_coop()) {
+        if (use_coop(ctx)) {
             dim3 grid((unsigned)((chunks + 3) / 4));
-            const bool ties = ctx->cloud[0].all_int && ctx->cloud[1].all_int;
-            const bool shift = jobs.j[0].slack32 != 0.0;       // an input of this pass is not fp32-exact (never with ties)
+            const bool shift = jobs.j[0].slack32 != 0.0;       // an input of this pass is not fp32-exact
             {
                 ProfScope ps(ctx, PCCM_K_GRID_QUERY);
                 if (self) {
-                    if (ties) hipLaunchKernelGGL((k_grid_query_coop<true, true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                    else if (shift) hipLaunchKernelGGL((k_grid_query_coop<true, false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                    else hipLaunchKernelGGL((k_grid_query_coop<true, false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    if (shift) hipLaunchKernelGGL((k_grid_query_coop<true, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    else hipLaunchKernelGGL((k_grid_query_coop<true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 } else {
-                    if (ties) hipLaunchKernelGGL((k_grid_query_coop<false, true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                    else if (shift) hipLaunchKernelGGL((k_grid_query_coop<false, false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                    else hipLaunchKernelGGL((k_grid_query_coop<false, false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    if (shift) hipLaunchKernelGGL((k_grid_query_coop<false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    else hipLaunchKernelGGL((k_grid_query_coop<false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 }
             }
             ProfScope pf(ctx, PCCM_K_GRID_FINISH);

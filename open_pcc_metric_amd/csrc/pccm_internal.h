@@ -68,6 +68,7 @@ struct Grid {                    // one geometry, both clouds (grid engine)
     bool boxed = false;            // the grid covers box_lo..box_hi (outliers trimmed) instead of the bounding box
     double box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};
     bool hostile = false;          // even so the cells are too crowded: PCCM_ENGINE_AUTO uses the brute engine
+    bool coop = true;              // cooperative ring-1 kernel (well-filled x-rows) or the per-thread search (surfaces, lattices)
     double sb = 0.0;               // size-biased points per cell the decision saw
     uint64_t iso_key = 0;          // pair the isolation count below was taken for
     int64_t isolated[2] = {0, 0};  // points of cloud k with nothing of the other cloud within kMaxRing cells

@@ -29,9 +29,6 @@ import click
               help="Which normal the point-to-plane projection uses.")
 @click.option("--extent", type=float, nargs=3, default=None, help="Extents of the PSNR peak box (skips the min-OBB).")
 def cli(ocloud, pcloud, color, hausdorff, point_to_plane, csv, device, engine, normal_index, extent) -> None:
-    import os
-    if "WORLD_SIZE" not in os.environ:
-        os.environ.setdefault("PCCM_NO_TORCH", "1")     # one process, one GPU: torch.distributed is not needed
     from .calculator import MetricCalculator
     from .cloud_pair import CloudPair
     from .io import read_point_cloud
