@@ -37,8 +37,6 @@ namespace pccm {
 
 constexpr int kMaxRing = 3;
 constexpr uint32_t kTailWaveMax = 16384;   // tails up to this many queries take the wave-per-query kernel
-constexpr int kScanItems = 8;                       // per thread in the prefix scan
-constexpr int kScanBlock = 256 * kScanItems;
 
 struct GridGeom {
     int dim[3];
@@ -111,101 +109,110 @@ __global__ __launch_bounds__(256) void k_grid_scatter(BuildJobs jobs, const uint
     *reinterpret_cast<double4 *>(&recs[pos]) = r;
 }
 
-// exclusive prefix sum of uint32 data[0..m) in place: block scan, offsets of the block totals, add back
-__global__ __launch_bounds__(256) void k_scan_block(uint32_t *__restrict__ data, int64_t m, uint32_t *__restrict__ blocksum)
+// Exclusive prefix sum of uint32 data[0..m) in place, ONE pass over the data (decoupled look-back): a tile of
+// 4096 counters per workgroup; tiles are handed out by an atomic ticket, so every predecessor of a running tile
+// is itself running or done and the look-back cannot starve.  Every tile publishes (status, value) in one
+// 64-bit word -- first its own total (status 1), then, once the totals of all earlier tiles are known, its
+// inclusive prefix (status 2); wave 0 of the tile looks back 64 predecessors at a time.  For surface-like
+// clouds the grid has ~20 cells per point and this scan, not the points, is what the build moves through HBM:
+// one read and one write of the counters instead of two each.
+// `state` = [ntiles] words followed by the ticket counter, all zero on entry (sort_by_cell's memset covers it).
+constexpr int kLbItems = 16;
+constexpr int kLbTile = 256 * kLbItems;
+
+static int64_t scan_tiles(int64_t m) { return (m + kLbTile - 1) / kLbTile; }
+// bytes a counter array of m entries needs including the scan's state behind it
+static size_t counters_bytes(int64_t m) { return (size_t)((m + 1) / 2 * 2) * sizeof(uint32_t) + (size_t)(scan_tiles(m) + 1) * 8; }
+static unsigned long long *scan_state(uint32_t *data, int64_t m) { return reinterpret_cast<unsigned long long *>(data + (m + 1) / 2 * 2); }
+
+__global__ __launch_bounds__(256) void k_scan_lookback(uint32_t *__restrict__ data, int64_t m, unsigned long long *__restrict__ state,
+                                                       int64_t ntiles)
 {
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t s_tile, s_prefix, wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)tid * kScanItems;
-    uint32_t v[kScanItems], tot = 0;
+    if (tid == 0) s_tile = (uint32_t)atomicAdd(&state[ntiles], 1ull);
+    __syncthreads();
+    const int64_t tile = s_tile;
+    const int64_t base = tile * kLbTile + (int64_t)tid * kLbItems;
+    uint32_t v[kLbItems], tot = 0;
+    if (base + kLbItems <= m) {
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        v[k] = (base + k < m) ? data[base + k] : 0u;
-        tot += v[k];
+        for (int k = 0; k < kLbItems; k += 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&data[base + k]);
+            v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kLbItems; ++k) v[k] = (base + k < m) ? data[base + k] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < kLbItems; ++k) tot += v[k];
     uint32_t inc = tot;                                   // inclusive scan of thread totals in the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(inc, off);
+        const uint32_t o = __shfl_up(inc, off);
         if (lane >= off) inc += o;
     }
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     uint32_t woff = 0;
     for (int k = 0; k < w; ++k) woff += wsum[k];
-    uint32_t run = woff + inc - tot;
+    const uint32_t agg = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (w == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&state[tile], ((tile == 0 ? 2ull : 1ull) << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        int64_t p = tile - 1;
+        while (p >= 0) {
+            const int64_t idx = p - lane;
+            const unsigned long long st = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                   : (2ull << 32);          // before the first tile: prefix 0
+            const uint32_t status = (uint32_t)(st >> 32), val = (uint32_t)st;
+            const unsigned long long incl = __ballot(status == 2u), empty = __ballot(status == 0u);
+            const int first = incl ? __ffsll((long long)incl) - 1 : 64;     // nearest predecessor with a full prefix
+            const unsigned long long nearer = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
+            if (empty & nearer) {                                            // someone nearer has not published yet
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            uint32_t part = (lane <= first) ? val : 0u;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        if (base + k < m) data[base + k] = run;
-        run += v[k];
-    }
-    if (tid == 255) blocksum[blockIdx.x] = woff + inc;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ blocksum, int64_t nb)
-{
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < nb; base += 1024) {
-        const int64_t i = base + tid;
-        const uint32_t v = i < nb ? blocksum[i] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            excl += part;
+            if (first < 64) break;
+            p -= 64;
         }
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        uint32_t woff = carry_s;
-        for (int k = 0; k < w; ++k) woff += wsum[k];
-        if (i < nb) blocksum[i] = woff + inc - v;
-        __syncthreads();
-        if (tid == 1023) carry_s = woff + inc;
-        __syncthreads();
+        if (lane == 0) {
+            if (tile > 0) __hip_atomic_store(&state[tile], (2ull << 32) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = excl;
+        }
     }
-}
-
-// add-back.  SUMMED: blocksum already holds exclusive offsets (k_scan_sums ran); otherwise every
-// block first adds up the totals of the blocks before it (few blocks: saves the k_scan_sums launch).
-template <bool SUMMED>
-__global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ data, int64_t m, const uint32_t *__restrict__ blocksum)
-{
-    __shared__ uint32_t part[4];
-    uint32_t add;
-    if (SUMMED) {
-        add = blocksum[blockIdx.x];
+    __syncthreads();
+    uint32_t run = s_prefix + woff + inc - tot;
+    if (base + kLbItems <= m) {
+#pragma unroll
+        for (int k = 0; k < kLbItems; k += 4) {
+            uint4 q;
+            q.x = run; run += v[k];
+            q.y = run; run += v[k + 1];
+            q.z = run; run += v[k + 2];
+            q.w = run; run += v[k + 3];
+            *reinterpret_cast<uint4 *>(&data[base + k]) = q;
+        }
     } else {
-        uint32_t s = 0;
-        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) s += blocksum[b];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-        __syncthreads();
-        add = part[0] + part[1] + part[2] + part[3];
+        for (int k = 0; k < kLbItems; ++k) {
+            if (base + k < m) data[base + k] = run;
+            run += v[k];
+        }
     }
-    const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanItems;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k)
-        if (base + k < m) data[base + k] += add;
 }
 
 static int exclusive_scan(pccm_ctx *ctx, uint32_t *data, int64_t m)
 {
-    const int64_t nb = (m + kScanBlock - 1) / kScanBlock;
-    int rc = ensure(ctx, ctx->g_blocksum, (size_t)nb * sizeof(uint32_t));
-    if (rc) return rc;
-    uint32_t *bs = (uint32_t *)ctx->g_blocksum.p;
-    hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, ctx->stream, data, m, bs);
-    if (nb > 1 && nb <= 2048) {
-        hipLaunchKernelGGL((k_scan_add<false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, data, m, (const uint32_t *)bs);
-    } else if (nb > 1) {
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, bs, nb);
-        hipLaunchKernelGGL((k_scan_add<true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, data, m, (const uint32_t *)bs);
-    }
+    const int64_t nt = scan_tiles(m);
+    hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nt), dim3(256), 0, ctx->stream, data, m, scan_state(data, m), nt);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
@@ -219,7 +226,7 @@ static int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g,
     if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)jobs.total * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->g_rank, (size_t)jobs.total * sizeof(uint32_t)))) return rc;
     uint32_t *cell_of = (uint32_t *)ctx->g_cell_of.p, *rank = (uint32_t *)ctx->g_rank.p;
-    PCCM_HIP(hipMemsetAsync(cs_all, 0, (size_t)cs_len * sizeof(uint32_t), ctx->stream));
+    PCCM_HIP(hipMemsetAsync(cs_all, 0, counters_bytes(cs_len), ctx->stream));      // counters + the scan's state behind them
     dim3 grid((unsigned)((jobs.total + 255) / 256));
     hipLaunchKernelGGL(k_grid_cells, grid, dim3(256), 0, ctx->stream, jobs, g, cell_of, rank);
     if ((rc = exclusive_scan(ctx, cs_all, cs_len))) return rc;
@@ -1016,7 +1023,7 @@ static int ensure_grid(pccm_ctx *ctx)
     choose_geometry(ctx, g, ncells, gr.scale);
     const int64_t n0 = ctx->cloud[0].n, n1 = ctx->cloud[1].n;
     int rc;
-    if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, gr.cell_start, counters_bytes(2 * (ncells + 1))))) return rc;
     if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;
     uint32_t *cs = (uint32_t *)gr.cell_start.p;
     BuildJobs jobs;
@@ -1192,7 +1199,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         // cell-sort the shards' rows: up to two directions per counting sort (same launches as a grid build)
         ProfScope ps(ctx, PCCM_K_GRID_BUILD);
         if ((rc = ensure(ctx, ctx->g_qrecs, (size_t)shard_total * sizeof(GridRec)))) return rc;
-        if ((rc = ensure(ctx, ctx->g_hist, (size_t)2 * (gr.ncells + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, ctx->g_hist, counters_bytes(2 * (gr.ncells + 1))))) return rc;
         GridRec *qbuf = (GridRec *)ctx->g_qrecs.p;
         for (int s0 = 0; s0 < nshard; s0 += 2) {
             const int cnt = nshard - s0 >= 2 ? 2 : 1;
