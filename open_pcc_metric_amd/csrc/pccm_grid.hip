@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_grid_scatter(BuildJobs jobs, const uint
 // clouds the grid has ~20 cells per point and this scan, not the points, is what the build moves through HBM:
 // one read and one write of the counters instead of two each.
 // `state` = [ntiles] words followed by the ticket counter, all zero on entry (sort_by_cell's memset covers it).
-constexpr int kLbItems = 16;
+constexpr int kLbItems = 64;
 constexpr int kLbTile = 256 * kLbItems;
 
 static int64_t scan_tiles(int64_t m) { return (m + kLbTile - 1) / kLbTile; }
