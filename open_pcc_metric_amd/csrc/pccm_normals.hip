@@ -127,13 +127,16 @@ __device__ void normal_from_neighbours(const double *__restrict__ x64, double qx
 }
 
 // one thread per point (in cell-sorted order); rings 0..kKnnMaxRing
-__global__ __launch_bounds__(256) void k_knn_normals(const GridRec *__restrict__ recs, int64_t qbase, int64_t n, KnnGeom g,
+// `todo` / `todo_count`: positions (within this cloud's slice) the wave kernel handed on; the threads stride over them
+__global__ __launch_bounds__(256) void k_knn_normals(const GridRec *__restrict__ recs, int64_t qbase, KnnGeom g,
                                                      const uint32_t *__restrict__ cell_start, const double *__restrict__ x64,
-                                                     int k, double *__restrict__ nrm_out, int32_t *__restrict__ open_list,
+                                                     int k, double *__restrict__ nrm_out, const uint32_t *__restrict__ todo,
+                                                     const uint32_t *__restrict__ todo_count, int32_t *__restrict__ open_list,
                                                      uint32_t *__restrict__ open_count)
 {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
+  const int64_t n = *todo_count;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n; u += (int64_t)gridDim.x * 256) {
+    const int64_t t = todo[u];
     const double4 qa = *reinterpret_cast<const double4 *>(&recs[qbase + t]);   // this cloud's slice of the combined array
     const double qx = qa.x, qy = qa.y, qz = qa.z;
     const int qrow = (int)(__double_as_longlong(qa.w) & 0xffffffffll);
@@ -183,6 +186,185 @@ __global__ __launch_bounds__(256) void k_knn_normals(const GridRec *__restrict__
     } else {
         open_list[atomicAdd(open_count, 1u)] = qrow;
     }
+  }
+}
+
+// ---- one wave per point -------------------------------------------------------------------------------
+// The per-thread search above keeps its k best in a private sorted list: ~85 insertions of ~15 shifts each per
+// point, all through scratch memory (12 ms per million points).  Here a wave takes one point: the lanes own the
+// x-runs of the cube [c-r, c+r]^3 (r = 2, then 3), the candidates' distances go to LDS, the k-th smallest is
+// found by a wave-wide quickselect (pivot = some staged distance inside the bracket, counted with ballots), ties at
+// the k-th distance go to the smaller rows, and the covariance of the selected points is accumulated by all lanes
+// and written out; k_normals_from_cov then solves the 3x3 eigenproblems one thread per point.  Same neighbour set
+// as the per-thread search (exact k-NN, (d2, row) order); the sums are taken in a different order.
+// Points the two cubes cannot settle, or with more than kWCap candidates, are passed on to k_knn_normals.
+constexpr int kWCap = 1024;
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_knn_cov_wave(const GridRec *__restrict__ recs, int64_t qbase, int64_t n, KnnGeom g,
+                                                      const uint32_t *__restrict__ cell_start, int k,
+                                                      double *__restrict__ cov_out /*[n][6] by row*/, int32_t *__restrict__ cnt_out,
+                                                      uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count)
+{
+    __shared__ double s_d[4][kWCap];
+    __shared__ uint32_t s_p[4][kWCap];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + w; t < n; t += nwaves) {
+        const double4 qa = *reinterpret_cast<const double4 *>(&recs[qbase + t]);          // wave-uniform
+        const double qx = qa.x, qy = qa.y, qz = qa.z;
+        const int qrow = (int)(__double_as_longlong(qa.w) & 0xffffffffll);
+        const int cx = ncell_coord(qx, g.org[0], g.inv_h[0], dimx);
+        const int cy = ncell_coord(qy, g.org[1], g.inv_h[1], dimy);
+        const int cz = ncell_coord(qz, g.org[2], g.inv_h[2], dimz);
+        bool done = false, giveup = false;
+        for (int r = 2; r <= 3 && !done && !giveup; ++r) {
+            // the lanes own the (2r+1)^2 x-runs of the cube
+            const int side = 2 * r + 1;
+            uint32_t s = 0, len = 0;
+            if (lane < side * side) {
+                const int z = cz + lane / side - r, y = cy + lane % side - r;
+                if (z >= 0 && z < dimz && y >= 0 && y < dimy) {
+                    const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
+                    const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
+                    s = cell_start[row + x0];
+                    len = cell_start[row + x1 + 1] - s;
+                }
+            }
+            uint32_t inc = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            const uint32_t T = __shfl(inc, 63);
+            if (T > (uint32_t)kWCap) { giveup = true; break; }
+            for (uint32_t u = 0; u < len; ++u) s_p[w][inc - len + u] = s + u;            // flatten the runs
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double dmax = 0.0;
+            for (uint32_t i = lane; i < T; i += 64) {
+                const double4 a = *reinterpret_cast<const double4 *>(&recs[s_p[w][i]]);
+                const double d = nd2(qx, qy, qz, a.x, a.y, a.z);
+                s_d[w][i] = d;
+                dmax = fmax(dmax, d);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off));
+            // stop rule of the grid engine for this cube
+            double L = INFINITY;
+            {
+                const double q[3] = {qx, qy, qz};
+                const int c[3] = {cx, cy, cz};
+                for (int a = 0; a < 3; ++a) {
+                    if (c[a] - r > 0) L = fmin(L, (q[a] - (g.org[a] + (double)(c[a] - r) * g.h[a])) - g.slack[a]);
+                    if (c[a] + r < g.dim[a] - 1) L = fmin(L, ((g.org[a] + (double)(c[a] + r + 1) * g.h[a]) - q[a]) - g.slack[a]);
+                }
+            }
+            const bool whole = (L == INFINITY);                     // the cube covers the grid: these are all the points
+            if (!whole && T < (uint32_t)k) continue;
+            // k-th smallest distance tau by quickselect over the staged values; bracket: #(d <= lo) < kk <= #(d <= hi)
+            const uint32_t kk = T < (uint32_t)k ? T : (uint32_t)k;
+            double lo = -1.0, hi = dmax;
+            for (;;) {
+                double cand = 0.0;
+                bool have = false;
+                for (uint32_t i = lane; i < T && !have; i += 64) {
+                    const double d = s_d[w][i];
+                    if (d > lo && d < hi) { cand = d; have = true; }
+                }
+                const unsigned long long m = __ballot(have);
+                if (!m) break;                                      // nothing strictly inside: tau = hi
+                const double x = __shfl(cand, __ffsll((long long)m) - 1);
+                uint32_t c = 0;
+                for (uint32_t i = lane; i < T; i += 64) c += (s_d[w][i] <= x) ? 1u : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+                if (c >= kk) hi = x; else lo = x;
+            }
+            const double tau = hi;
+            if (!whole && !(L > 0.0 && tau < L * L * (1.0 - 0x1.0p-30))) continue;        // try the next cube
+            // ties at tau: the smaller rows win
+            uint32_t below = 0, equal = 0;
+            for (uint32_t i = lane; i < T; i += 64) {
+                const double d = s_d[w][i];
+                below += d < tau ? 1u : 0u;
+                equal += d == tau ? 1u : 0u;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                below += __shfl_xor(below, off);
+                equal += __shfl_xor(equal, off);
+            }
+            int row_cut = 0x7fffffff;                                // rows <= row_cut among the tied are taken
+            if (below + equal > kk) {
+                int last = -1;
+                for (uint32_t need = kk - below; need > 0; --need) {                       // need-th smallest tied row
+                    int best = 0x7fffffff;
+                    for (uint32_t i = lane; i < T; i += 64)
+                        if (s_d[w][i] == tau) {
+                            const int row = recs[s_p[w][i]].idx;
+                            if (row > last && row < best) best = row;
+                        }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
+                    last = best;
+                }
+                row_cut = last;
+            }
+            double m0 = 0, m1 = 0, m2 = 0, s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+            for (uint32_t i = lane; i < T; i += 64) {
+                const double d = s_d[w][i];
+                if (d > tau) continue;
+                const double4 a = *reinterpret_cast<const double4 *>(&recs[s_p[w][i]]);
+                if (d == tau && (int)(__double_as_longlong(a.w) & 0xffffffffll) > row_cut) continue;
+                const double dx = a.x - qx, dy = a.y - qy, dz = a.z - qz;
+                m0 += dx; m1 += dy; m2 += dz;
+                s00 += dx * dx; s01 += dx * dy; s02 += dx * dz; s11 += dy * dy; s12 += dy * dz; s22 += dz * dz;
+            }
+            m0 = wave_sum_f64(m0); m1 = wave_sum_f64(m1); m2 = wave_sum_f64(m2);
+            s00 = wave_sum_f64(s00); s01 = wave_sum_f64(s01); s02 = wave_sum_f64(s02);
+            s11 = wave_sum_f64(s11); s12 = wave_sum_f64(s12); s22 = wave_sum_f64(s22);
+            if (lane == 0) {
+                const double inv = 1.0 / (double)kk;
+                m0 *= inv; m1 *= inv; m2 *= inv;
+                double *o = cov_out + 6 * (int64_t)qrow;
+                o[0] = s00 * inv - m0 * m0; o[1] = s01 * inv - m0 * m1; o[2] = s02 * inv - m0 * m2;
+                o[3] = s11 * inv - m1 * m1; o[4] = s12 * inv - m1 * m2; o[5] = s22 * inv - m2 * m2;
+                cnt_out[qrow] = (int)kk;
+            }
+            done = true;
+        }
+        if (!done && lane == 0) {
+            cnt_out[qrow] = -1;                                       // k_knn_normals writes this normal itself
+            todo[atomicAdd(todo_count, 1u)] = (uint32_t)t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // LDS is reused by the next point
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_normals_from_cov(const double *__restrict__ cov, const int32_t *__restrict__ cnt, int64_t n,
+                                                          double *__restrict__ nrm_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = cnt[i];
+    if (c < 0) return;                                               // settled by the per-thread kernel
+    double nn[3] = {0.0, 0.0, 1.0};
+    const double *a = cov + 6 * i;
+    if (c >= 3) smallest_eigenvector(a[0], a[1], a[2], a[3], a[4], a[5], nn);
+    nrm_out[3 * i] = nn[0];
+    nrm_out[3 * i + 1] = nn[1];
+    nrm_out[3 * i + 2] = nn[2];
 }
 
 // isolated points: exact k-NN by a full scan, one workgroup per point.  Every thread keeps the k best of its
@@ -254,15 +436,25 @@ int estimate_normals(pccm_ctx *ctx, int which, int k)
     c.n_nrm = c.n;
     for (int d = 0; d < 3; ++d) ctx->nn_gen[d]++;      // pending D2 reductions would use stale normals
     ctx->epoch++;
-    if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)c.n * sizeof(uint32_t)))) return rc;   // reused as the open list
+    if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)c.n * sizeof(uint32_t)))) return rc;   // reused: points left to the full scan
+    if ((rc = ensure(ctx, ctx->g_rank, (size_t)c.n * sizeof(uint32_t)))) return rc;      // reused: points left to the per-thread search
+    if ((rc = ensure(ctx, ctx->val, (size_t)c.n * (6 * sizeof(double) + sizeof(int32_t))))) return rc;   // covariances + counts
     if ((rc = ensure(ctx, ctx->g_blocksum, 256))) return rc;
-    uint32_t *open_count = (uint32_t *)ctx->g_blocksum.p;
-    PCCM_HIP(hipMemsetAsync(open_count, 0, sizeof(uint32_t), ctx->stream));
+    uint32_t *open_count = (uint32_t *)ctx->g_blocksum.p, *todo_count = open_count + 1;
+    PCCM_HIP(hipMemsetAsync(open_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+    double *cov = (double *)ctx->val.p;
+    int32_t *cnt = (int32_t *)(cov + 6 * c.n);
     // cell_start holds positions in the combined record array: pass the array base plus this cloud's offset
     const uint32_t *cs = (const uint32_t *)gr.cell_start.p + (which ? gr.ncells + 1 : 0);
-    hipLaunchKernelGGL(k_knn_normals, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const GridRec *)gr.recs.p, (int64_t)(which ? gr.n[0] : 0), c.n, g, cs, (const double *)c.xyz64, k,
-                       c.nrm64, (int32_t *)ctx->g_cell_of.p, open_count);
+    const int64_t qbase = which ? gr.n[0] : 0;
+    const int64_t wblocks = (c.n + 3) / 4;
+    hipLaunchKernelGGL(k_knn_cov_wave, dim3((unsigned)(wblocks < 16384 ? wblocks : 16384)), dim3(256), 0, ctx->stream,
+                       (const GridRec *)gr.recs.p, qbase, c.n, g, cs, k, cov, cnt, (uint32_t *)ctx->g_rank.p, todo_count);
+    hipLaunchKernelGGL(k_normals_from_cov, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)cov,
+                       (const int32_t *)cnt, c.n, c.nrm64);
+    hipLaunchKernelGGL(k_knn_normals, dim3(2048), dim3(256), 0, ctx->stream, (const GridRec *)gr.recs.p, qbase, g, cs,
+                       (const double *)c.xyz64, k, c.nrm64, (const uint32_t *)ctx->g_rank.p, (const uint32_t *)todo_count,
+                       (int32_t *)ctx->g_cell_of.p, open_count);
     hipLaunchKernelGGL(k_knn_normals_full, dim3(512), dim3(256), 0, ctx->stream, (const double *)c.xyz64, c.n, k,
                        (const int32_t *)ctx->g_cell_of.p, (const uint32_t *)open_count, c.nrm64);
     PCCM_HIP(hipGetLastError());
