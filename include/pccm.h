@@ -180,6 +180,13 @@ int pccm_color_reduce(pccm_ctx *ctx, int dir, int scheme, double scale, const in
 int pccm_color_rows(pccm_ctx *ctx, int dir, int scheme, double scale, int what, const int32_t *rows, int64_t nrows,
                     double *out);
 
+/* The frame search behind CloudPair.get_extent() (cloud_pair.py:111-112, Open3D's minimal oriented bounding box):
+ * verts = the nv vertices of the convex hull of cloud A, tri = its nt triangles as vertex coordinates [nt][3][3]
+ * (the hull itself is Qhull on the host, as in Open3D).  For every triangle the axis-aligned extents of the hull
+ * vertices in the triangle's frame (x along its first edge, z along its normal) are evaluated on the device;
+ * ext_out = the extents of the frame with the smallest volume (first one on ties), *vol_out its volume. */
+int pccm_obb_frames(pccm_ctx *ctx, const double *verts, int64_t nv, const double *tri, int64_t nt, double ext_out[3], double *vol_out);
+
 /* Utility behind pccm_color_reduce: out[c] = left-to-right fp64 sum of column c of three non-negative
  * host columns cols[3][n] -- what np.add.reduce(a, axis=0) returns for the (n, 3) array a = cols.T --
  * evaluated on the device without the dependent chain (csrc/pccm_color.hip). */

@@ -31,7 +31,7 @@ SYMBOLS = (
     "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
-    "pccm_set_colors", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum",
+    "pccm_set_colors", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames",
     "pccm_color_transform", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
@@ -98,6 +98,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_set_colors.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_color_reduce.argtypes = [vp, i32, i32, ctypes.c_double, vp, i64, dp, dp]
     lib.pccm_seq_colsum.argtypes = [vp, vp, i64, dp]
+    lib.pccm_obb_frames.argtypes = [vp, vp, i64, vp, i64, dp, dp]
     lib.pccm_color_rows.argtypes = [vp, i32, i32, ctypes.c_double, i32, vp, i64, vp]
     lib.pccm_graph_begin.argtypes = [vp]
     lib.pccm_graph_end.argtypes = [vp, ctypes.POINTER(i32)]
@@ -231,6 +232,17 @@ class Engine:
         sums, maxs = (ctypes.c_double * 3)(), (ctypes.c_double * 3)()
         _check(self._lib.pccm_color_reduce(self._ctx, int(direction), COLOR_SCHEMES[scheme], float(scale), ptr, n, sums, maxs))
         return np.array(sums[:], dtype=np.float64), np.array(maxs[:], dtype=np.float64)
+
+    def obb_frames(self, hull_vertices, hull_triangles):
+        """-> (extents, volume) of the smallest box over the frames of the hull's triangles (pccm_obb_frames)."""
+        v = np.ascontiguousarray(hull_vertices, dtype=np.float64)
+        t = np.ascontiguousarray(hull_triangles, dtype=np.float64)
+        if v.ndim != 2 or v.shape[1] != 3 or t.ndim != 3 or t.shape[1:] != (3, 3):
+            raise ValueError("hull_vertices must be (H, 3) and hull_triangles (T, 3, 3)")
+        ext, vol = (ctypes.c_double * 3)(), ctypes.c_double()
+        _check(self._lib.pccm_obb_frames(self._ctx, v.ctypes.data_as(ctypes.c_void_p), v.shape[0], t.ctypes.data_as(ctypes.c_void_p),
+                                         t.shape[0], ext, ctypes.byref(vol)))
+        return np.array(ext[:], dtype=np.float64), vol.value
 
     def seq_colsum(self, columns) -> np.ndarray:
         """np.add.reduce(a, axis=0) of a non-negative (N, 3) array, bit for bit, on the device."""

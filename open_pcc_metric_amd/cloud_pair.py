@@ -403,7 +403,7 @@ class CloudPair:
 
     def get_extent(self):
         if self._extent is None:
-            self._extent = minimal_obb_extent(_host_rows(self.clouds[0].points))
+            self._extent = minimal_obb_extent(_host_rows(self.clouds[0].points), self._engine)
         return self._extent
 
     def get_normals(self, which: int):

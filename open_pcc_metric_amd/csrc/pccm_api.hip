@@ -432,6 +432,33 @@ int pccm_color_reduce(pccm_ctx *ctx, int dir, int scheme, double scale, const in
     return PCCM_OK;
 }
 
+int pccm_obb_frames(pccm_ctx *ctx, const double *verts, int64_t nv, const double *tri, int64_t nt, double ext_out[3], double *vol_out)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (!verts || !tri || !ext_out || nv <= 0 || nt <= 0) return fail(PCCM_E_ARG, "bad argument");
+    // scratch: [nv][3] vertices | [nt][9] triangles | [nt][3] extents | [nt] volumes
+    const size_t bytes = ((size_t)nv * 3 + (size_t)nt * 13) * sizeof(double);
+    int rc = ensure(ctx, ctx->color_cols, bytes);
+    if (rc) return rc;
+    double *dv = (double *)ctx->color_cols.p, *dt = dv + 3 * nv, *de = dt + 9 * nt, *dvol = de + 3 * nt;
+    PCCM_HIP(hipMemcpyAsync(dv, verts, (size_t)nv * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PCCM_HIP(hipMemcpyAsync(dt, tri, (size_t)nt * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_obb_frames(ctx, dv, nv, dt, nt, de, dvol);
+    if (rc) return rc;
+    std::vector<double> ext((size_t)nt * 3), vol((size_t)nt);
+    PCCM_HIP(hipMemcpyAsync(ext.data(), de, ext.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipMemcpyAsync(vol.data(), dvol, vol.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t best = -1;
+    for (int64_t t = 0; t < nt; ++t)                      // first smallest finite volume (np.argmin's choice)
+        if (vol[t] < INFINITY && (best < 0 || vol[t] < vol[best])) best = t;
+    if (best < 0) return fail(PCCM_E_ARG, "degenerate convex hull: no triangle spans a box of finite volume");
+    for (int k = 0; k < 3; ++k) ext_out[k] = ext[3 * best + k];
+    if (vol_out) *vol_out = vol[best];
+    return PCCM_OK;
+}
+
 int pccm_seq_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double out[3])
 {
     CHECK_CTX(ctx);

@@ -237,6 +237,9 @@ int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const N
 
 double np_pairwise_sum(const double *a, int64_t n);
 
+// minimal-OBB frame search (pccm_obb.hip)
+int launch_obb_frames(pccm_ctx *ctx, const double *verts, int64_t nv, const double *tri, int64_t nt, double *ext_out, double *vol_out);
+
 // colour columns (pccm_color.hip)
 int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, const int32_t *rows, int64_t n,
                       int64_t n_other, int scheme, double scale, int what, double *out,

@@ -145,6 +145,32 @@ def point_to_plane(iter_pts, search_pts, nn_idx, other_normals, *, normal_index:
     return out
 
 
+def minimal_obb_extent(points) -> np.ndarray:
+    """CloudExtent, cloud_pair.py:111-112: extents of the minimal oriented bounding box as Open3D 0.18 searches
+    for it (Qhull hull; for every hull triangle the box of the hull vertices in the triangle's frame -- x along
+    its first edge, z along its normal; smallest volume, first one on ties).  NumPy, O(H x T): small clouds only."""
+    from scipy.spatial import ConvexHull
+
+    pts = _f64(points)
+    hull = ConvexHull(pts)
+    verts, tri = pts[hull.vertices], pts[hull.simplices]
+    best_vol, best_ext = np.inf, None
+    for a, b, c in tri:
+        u, v = b - a, c - a
+        w = np.cross(u, v)
+        v = np.cross(w, u)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            frame = np.stack([x / np.sqrt(np.sum(x * x)) for x in (u, v, w)])
+        loc = (verts - a) @ frame.T
+        ext = loc.max(axis=0) - loc.min(axis=0)
+        vol = ext.prod()
+        if np.isfinite(vol) and vol < best_vol:
+            best_vol, best_ext = float(vol), ext
+    if best_ext is None:
+        raise RuntimeError("degenerate convex hull")
+    return best_ext
+
+
 COLOR_SCHEMES = {"rgb": 0, "ycc": 1, "yuv": 2}
 
 

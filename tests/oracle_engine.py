@@ -65,6 +65,21 @@ class OracleEngine:
         return scale * (_signed_rows(own, zeros, np.zeros(len(own), np.int64), scheme)
                         - _signed_rows(other[rows], zeros, np.zeros(len(rows), np.int64), scheme))
 
+    def obb_frames(self, hull_vertices, hull_triangles):
+        best_vol, best_ext = np.inf, None
+        for a, b, c in np.asarray(hull_triangles, dtype=np.float64):
+            u, v = b - a, c - a
+            w = np.cross(u, v)
+            v = np.cross(w, u)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                frame = np.stack([x / np.sqrt(np.sum(x * x)) for x in (u, v, w)])
+            loc = (np.asarray(hull_vertices) - a) @ frame.T
+            ext = loc.max(axis=0) - loc.min(axis=0)
+            vol = ext.prod()
+            if np.isfinite(vol) and vol < best_vol:
+                best_vol, best_ext = float(vol), ext
+        return best_ext, best_vol
+
     def set_shard(self, rank, world):
         self.rank, self.world = rank, world
         self.res.clear()
