@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_knn_normals(const GridRec *__restrict__
 // and written out; k_normals_from_cov then solves the 3x3 eigenproblems one thread per point.  Same neighbour set
 // as the per-thread search (exact k-NN, (d2, row) order); the sums are taken in a different order.
 // Points the two cubes cannot settle, or with more than kWCap candidates, are passed on to k_knn_normals.
-constexpr int kWCap = 1024;
+constexpr int kWCap = 512;
 
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
