@@ -1,0 +1,81 @@
+"""Developer scratch: randomised differential test of the search engines against the oracle (GPU box).
+
+    python scripts/dev_fuzz.py SECONDS [SEED]
+"""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_pcc_metric_amd import _native as nat
+from oracle import oracle as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+
+
+def make(rng, n, kind):
+    if kind == "uniform32":
+        return rng.random((n, 3), dtype=np.float32).astype(np.float64)
+    if kind == "uniform64":
+        return rng.random((n, 3)) * rng.choice([1.0, 1e-3, 1e4])
+    if kind == "offset64":
+        return rng.random((n, 3)) * 50 + rng.choice([1e3, 1e5, 4e6]) * rng.random(3)
+    if kind == "lattice":
+        return rng.integers(0, rng.choice([4, 16, 64, 1024]), (n, 3)).astype(np.float64)
+    if kind == "surface":
+        v = rng.standard_normal((n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True) + 1e-30
+        p = 100 + 60 * v
+        return np.round(p) if rng.random() < 0.5 else p.astype(np.float32).astype(np.float64)
+    if kind == "clusters":
+        c = rng.random((max(1, n // 200), 3)) * 100
+        return (c[rng.integers(0, len(c), n)] + rng.normal(0, 0.05, (n, 3))).astype(np.float32).astype(np.float64)
+    if kind == "outliers":
+        p = rng.random((n, 3), dtype=np.float32).astype(np.float64)
+        k = max(1, n // 500)
+        p[:k] = (rng.random((k, 3)) - 0.5) * rng.choice([1e2, 1e4, 1e6])
+        return p
+    if kind == "planar":
+        p = rng.random((n, 3)); p[:, rng.integers(0, 3)] = 0.5
+        return p
+    if kind == "dups":
+        base = rng.random((max(1, n // 50), 3), dtype=np.float32).astype(np.float64)
+        return base[rng.integers(0, len(base), n)]
+    raise KeyError(kind)
+
+
+KINDS = ["uniform32", "uniform64", "offset64", "lattice", "surface", "clusters", "outliers", "planar", "dups"]
+if __name__ != "__main__":
+    budget = 0.0
+e = nat.Engine(0) if __name__ == "__main__" else None
+t_end = time.time() + budget
+it = fails = 0
+while __name__ == "__main__" and time.time() < t_end:
+    rng = np.random.default_rng(seed0 * 1000003 + it)
+    it += 1
+    na = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 1000, 4097, 20000, 60000]))
+    nb = int(rng.choice([1, 2, 5, 64, 129, 777, 1000, 8192, 8193, 30000, 50000]))
+    ka, kb = rng.choice(KINDS), rng.choice(KINDS)
+    a, b = make(rng, na, ka), make(rng, nb, kb)
+    if rng.random() < 0.3:
+        b = b + a[rng.integers(0, na)] - b[0]            # make the clouds meet somewhere
+    eng = str(rng.choice(["auto", "grid", "grid", "brute"]))
+    try:
+        e.set_cloud(0, a); e.set_cloud(1, b)
+        e.nn_pair(eng)
+        e.nn(nat.DIR_SELF, eng)
+        for d, (q, r, skip) in enumerate(((a, b, False), (b, a, False), (a, a, True))):
+            idx, d2 = e.fetch_nn(d)
+            if skip and na < 2:
+                ok = bool(np.all(idx == -1) and np.all(d2 == 0))
+            else:
+                oi, od = orc.nn(q, r, skip_same_index=skip, method="kdtree")
+                ok = np.array_equal(d2, od) and np.array_equal(idx, oi)
+            if not ok:
+                fails += 1
+                print(f"MISMATCH it={it} seed={seed0} dir={d} eng={eng} A={ka}:{na} B={kb}:{nb}", flush=True)
+    except Exception as ex:                               # noqa: BLE001
+        fails += 1
+        print(f"ERROR it={it} seed={seed0} eng={eng} A={ka}:{na} B={kb}:{nb}: {type(ex).__name__}: {ex}", flush=True)
+    if it % 50 == 0:
+        print(f"... {it} cases, {fails} failures", flush=True)
+if __name__ == "__main__":
+    print(f"FUZZ DONE: {it} cases, {fails} failures")
