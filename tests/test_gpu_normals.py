@@ -54,6 +54,17 @@ def test_normals_uniform_volume_and_outliers():
     check_normals(pts)
 
 
+def test_normals_on_voxelised_surfaces_with_exact_ties():
+    """Integer coordinates: the k-th neighbour distance is tied almost everywhere, so the (d2, row) order of the
+    selection decides the neighbour set."""
+    rng = np.random.default_rng(8)
+    v = rng.standard_normal((40000, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    check_normals(np.unique(np.round(64 + 50 * v * [1.0, 0.7, 0.5]), axis=0))
+    u = rng.integers(0, 120, (15000, 2)).astype(np.float64)
+    sheet = np.unique(np.column_stack([u, np.round(0.3 * u[:, 0] + 4 * np.sin(u[:, 1] / 9.0))]), axis=0)
+    check_normals(sheet)
+
+
 def test_normals_tiny_and_degenerate_clouds():
     e = nat.Engine(0)
     two = np.array([[0.0, 0, 0], [1, 1, 1]])
