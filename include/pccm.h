@@ -53,7 +53,7 @@ extern "C" {
 #define PCCM_DIR_SELF 2
 
 /* nearest-neighbour engines (all exact; they differ only in speed) */
-#define PCCM_ENGINE_AUTO 0
+#define PCCM_ENGINE_AUTO 0  /* the grid, unless the pair of clouds is one no uniform grid can separate (clumps, partial overlap) */
 #define PCCM_ENGINE_BRUTE 1 /* LDS-tiled fp32 scan + fp64 certification/refine */
 #define PCCM_ENGINE_GRID 2  /* uniform-grid ring search */
 
@@ -70,7 +70,7 @@ extern "C" {
 #define PCCM_K_INGEST 0
 #define PCCM_K_SCAN 1     /* brute-force fp32 scan (dominant kernel of PCCM_ENGINE_BRUTE) */
 #define PCCM_K_REFINE 2   /* fp64 certification + winner refine */
-#define PCCM_K_FALLBACK 3 /* exact rescan of uncertified queries */
+#define PCCM_K_FALLBACK 3 /* exact rescan of flagged queries (uncertified fp32 winners; queries the grid's rings left open) */
 #define PCCM_K_POINT 4    /* fused gather + error vector + projection */
 #define PCCM_K_REDUCE 5   /* leaf sums / max / min */
 #define PCCM_K_GRID_BUILD 6
