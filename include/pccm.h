@@ -187,6 +187,15 @@ int pccm_color_rows(pccm_ctx *ctx, int dir, int scheme, double scale, int what, 
  * ext_out = the extents of the frame with the smallest volume (first one on ties), *vol_out its volume. */
 int pccm_obb_frames(pccm_ctx *ctx, const double *verts, int64_t nv, const double *tri, int64_t nt, double ext_out[3], double *vol_out);
 
+/* Thinning cloud `which` before the host's Qhull run (get_minimal_oriented_bounding_box, cloud_pair.py:111-112):
+ * pccm_extreme_rows  rows_out[k] = row of (about) the farthest point of the cloud along dirs[k] (ndirs <= 1024, fp32);
+ * pccm_rows_outside  the rows (unordered) of all points x with n.x + off > -margin for some plane (n, off) of
+ *                    planes[nplanes][4] -- Qhull's convention: n.x + off <= 0 inside.  With the facets of the hull of
+ *                    the extreme points as planes, every point NOT reported lies strictly inside the hull of other
+ *                    points of the cloud and cannot be a vertex of the cloud's hull.  rows_out must hold n rows. */
+int pccm_extreme_rows(pccm_ctx *ctx, int which, const float *dirs, int ndirs, int32_t *rows_out);
+int pccm_rows_outside(pccm_ctx *ctx, int which, const double *planes, int nplanes, double margin, int32_t *rows_out, int64_t *count);
+
 /* Utility behind pccm_color_reduce: out[c] = left-to-right fp64 sum of column c of three non-negative
  * host columns cols[3][n] -- what np.add.reduce(a, axis=0) returns for the (n, 3) array a = cols.T --
  * evaluated on the device without the dependent chain (csrc/pccm_color.hip). */

@@ -31,7 +31,7 @@ SYMBOLS = (
     "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
-    "pccm_set_colors", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames",
+    "pccm_set_colors", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
     "pccm_color_transform", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
@@ -99,6 +99,8 @@ def load() -> ctypes.CDLL:
     lib.pccm_color_reduce.argtypes = [vp, i32, i32, ctypes.c_double, vp, i64, dp, dp]
     lib.pccm_seq_colsum.argtypes = [vp, vp, i64, dp]
     lib.pccm_obb_frames.argtypes = [vp, vp, i64, vp, i64, dp, dp]
+    lib.pccm_extreme_rows.argtypes = [vp, i32, vp, i32, vp]
+    lib.pccm_rows_outside.argtypes = [vp, i32, vp, i32, ctypes.c_double, vp, ctypes.POINTER(i64)]
     lib.pccm_color_rows.argtypes = [vp, i32, i32, ctypes.c_double, i32, vp, i64, vp]
     lib.pccm_graph_begin.argtypes = [vp]
     lib.pccm_graph_end.argtypes = [vp, ctypes.POINTER(i32)]
@@ -232,6 +234,23 @@ class Engine:
         sums, maxs = (ctypes.c_double * 3)(), (ctypes.c_double * 3)()
         _check(self._lib.pccm_color_reduce(self._ctx, int(direction), COLOR_SCHEMES[scheme], float(scale), ptr, n, sums, maxs))
         return np.array(sums[:], dtype=np.float64), np.array(maxs[:], dtype=np.float64)
+
+    def extreme_rows(self, which: int, directions) -> np.ndarray:
+        """Rows of the (about) farthest points of cloud ``which`` along each of <= 1024 directions."""
+        d = np.ascontiguousarray(directions, dtype=np.float32)
+        out = np.empty(d.shape[0], dtype=np.int32)
+        _check(self._lib.pccm_extreme_rows(self._ctx, int(which), d.ctypes.data_as(ctypes.c_void_p), d.shape[0],
+                                           out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def rows_outside(self, which: int, planes, margin: float) -> np.ndarray:
+        """Rows of cloud ``which`` not strictly inside the polytope ``n.x + off <= 0`` (planes: (F, 4), Qhull's equations)."""
+        p = np.ascontiguousarray(planes, dtype=np.float64)
+        out = np.empty(self._n[which], dtype=np.int32)
+        cnt = ctypes.c_int64()
+        _check(self._lib.pccm_rows_outside(self._ctx, int(which), p.ctypes.data_as(ctypes.c_void_p), p.shape[0], float(margin),
+                                           out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(cnt)))
+        return out[:cnt.value]
 
     def obb_frames(self, hull_vertices, hull_triangles):
         """-> (extents, volume) of the smallest box over the frames of the hull's triangles (pccm_obb_frames)."""

@@ -459,6 +459,52 @@ int pccm_obb_frames(pccm_ctx *ctx, const double *verts, int64_t nv, const double
     return PCCM_OK;
 }
 
+int pccm_extreme_rows(pccm_ctx *ctx, int which, const float *dirs, int ndirs, int32_t *rows_out)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if ((which != 0 && which != 1) || !dirs || !rows_out || ndirs <= 0 || ndirs > 1024) return fail(PCCM_E_ARG, "bad argument (1..1024 directions)");
+    const Cloud &c = ctx->cloud[which];
+    if (c.n <= 0) return fail(PCCM_E_STATE, "cloud %d is not set", which);
+    int rc = ensure(ctx, ctx->color_cols, (size_t)ndirs * (3 * sizeof(float) + sizeof(unsigned long long)));
+    if (rc) return rc;
+    unsigned long long *best = (unsigned long long *)ctx->color_cols.p;
+    float *ddirs = (float *)(best + ndirs);
+    PCCM_HIP(hipMemsetAsync(best, 0, (size_t)ndirs * sizeof(unsigned long long), ctx->stream));
+    PCCM_HIP(hipMemcpyAsync(ddirs, dirs, (size_t)ndirs * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_extreme_rows(ctx, c.xyz64, c.n, ddirs, ndirs, best);
+    if (rc) return rc;
+    std::vector<unsigned long long> h((size_t)ndirs);
+    PCCM_HIP(hipMemcpyAsync(h.data(), best, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < ndirs; ++k) rows_out[k] = (int32_t)(h[k] & 0xffffffffull);
+    return PCCM_OK;
+}
+
+int pccm_rows_outside(pccm_ctx *ctx, int which, const double *planes, int nplanes, double margin, int32_t *rows_out, int64_t *count)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if ((which != 0 && which != 1) || !planes || !rows_out || !count || nplanes <= 0 || !(margin >= 0.0)) return fail(PCCM_E_ARG, "bad argument");
+    const Cloud &c = ctx->cloud[which];
+    if (c.n <= 0) return fail(PCCM_E_STATE, "cloud %d is not set", which);
+    int rc = ensure(ctx, ctx->color_cols, (size_t)nplanes * 4 * sizeof(double) + (size_t)c.n * sizeof(int32_t) + 16);
+    if (rc) return rc;
+    double *dpl = (double *)ctx->color_cols.p;
+    unsigned int *dcount = (unsigned int *)(dpl + 4 * (size_t)nplanes);
+    int32_t *drows = (int32_t *)(dcount + 4);
+    PCCM_HIP(hipMemcpyAsync(dpl, planes, (size_t)nplanes * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PCCM_HIP(hipMemsetAsync(dcount, 0, sizeof(unsigned int), ctx->stream));
+    rc = launch_outside_planes(ctx, c.xyz64, c.n, dpl, nplanes, margin, drows, dcount);
+    if (rc) return rc;
+    unsigned int hc = 0;
+    PCCM_HIP(hipMemcpyAsync(&hc, dcount, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    if (hc) PCCM_HIP(hipMemcpy(rows_out, drows, (size_t)hc * sizeof(int32_t), hipMemcpyDeviceToHost));
+    *count = (int64_t)hc;
+    return PCCM_OK;
+}
+
 int pccm_seq_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double out[3])
 {
     CHECK_CTX(ctx);

@@ -239,6 +239,9 @@ double np_pairwise_sum(const double *a, int64_t n);
 
 // minimal-OBB frame search (pccm_obb.hip)
 int launch_obb_frames(pccm_ctx *ctx, const double *verts, int64_t nv, const double *tri, int64_t nt, double *ext_out, double *vol_out);
+int launch_extreme_rows(pccm_ctx *ctx, const double *x64, int64_t n, const float *dirs, int ndirs, unsigned long long *best);
+int launch_outside_planes(pccm_ctx *ctx, const double *x64, int64_t n, const double *planes, int nplanes, double margin,
+                          int32_t *rows_out, unsigned int *count);
 
 // colour columns (pccm_color.hip)
 int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, const int32_t *rows, int64_t n,

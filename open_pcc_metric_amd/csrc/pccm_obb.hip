@@ -73,3 +73,91 @@ int launch_obb_frames(pccm_ctx *ctx, const double *verts, int64_t nv, const doub
 }
 
 }  // namespace pccm
+
+// ---- thinning the cloud before Qhull -----------------------------------------------------------------------
+// Qhull's time goes into the N input points, almost all of which lie deep inside the hull.  Two kernels let the
+// host hand it only points that can still be hull vertices -- exactly, not approximately:
+//   k_extreme_rows    for K directions the row of (about) the farthest point: these K points span an inner polytope;
+//   k_outside_planes  the rows of all points that are not strictly inside that polytope (its facets come back from
+//                     a tiny Qhull run on the K points).  A point strictly inside the hull of other points of the
+//                     cloud is not a vertex of the cloud's hull, so dropping it does not change the hull.
+// Which K points are picked does not matter for correctness (any subset of the cloud gives a valid inner polytope),
+// so the extremes are chosen in fp32.
+namespace pccm {
+
+constexpr int kMaxDirs = 1024;
+
+__global__ __launch_bounds__(256) void k_extreme_rows(const double *__restrict__ x64, int64_t n, const float *__restrict__ dirs, int ndirs,
+                                                      unsigned long long *__restrict__ best /*[ndirs]: (ordered dot << 32) | row*/)
+{
+    __shared__ float s_dir[kMaxDirs * 3];
+    __shared__ unsigned long long s_best[kMaxDirs];
+    for (int k = threadIdx.x; k < ndirs * 3; k += 256) s_dir[k] = dirs[k];
+    for (int k = threadIdx.x; k < ndirs; k += 256) s_best[k] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 255) / 256 * 256; i += (int64_t)gridDim.x * 256) {
+        const bool live = i < n;
+        const float x = live ? (float)x64[3 * i] : 0.f, y = live ? (float)x64[3 * i + 1] : 0.f, z = live ? (float)x64[3 * i + 2] : 0.f;
+        for (int k = 0; k < ndirs; ++k) {
+            const float d = s_dir[3 * k] * x + s_dir[3 * k + 1] * y + s_dir[3 * k + 2] * z;
+            uint32_t b = __float_as_uint(d);
+            b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                      // order-preserving key
+            unsigned long long key = live ? (((unsigned long long)b << 32) | (unsigned long long)(uint32_t)i) : 0ull;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(key, off);
+                key = o > key ? o : key;
+            }
+            if (lane == 0 && key > s_best[k]) atomicMax(&s_best[k], key);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ndirs; k += 256)
+        if (s_best[k]) atomicMax(&best[k], s_best[k]);
+}
+
+__global__ __launch_bounds__(256) void k_outside_planes(const double *__restrict__ x64, int64_t n, const double *__restrict__ planes,
+                                                        int nplanes, double margin, int32_t *__restrict__ rows_out,
+                                                        unsigned int *__restrict__ count)
+{
+    __shared__ double s_pl[512 * 4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    const double x = live ? x64[3 * i] : 0.0, y = live ? x64[3 * i + 1] : 0.0, z = live ? x64[3 * i + 2] : 0.0;
+    bool outside = false;
+    for (int base = 0; base < nplanes; base += 512) {
+        const int m = nplanes - base < 512 ? nplanes - base : 512;
+        __syncthreads();
+        for (int k = threadIdx.x; k < 4 * m; k += 256) s_pl[k] = planes[4 * base + k];
+        __syncthreads();
+        if (!outside)
+            for (int k = 0; k < m; ++k)
+                if (s_pl[4 * k] * x + s_pl[4 * k + 1] * y + s_pl[4 * k + 2] * z + s_pl[4 * k + 3] > -margin) {   // Qhull: n.x + off <= 0 inside
+                    outside = true;
+                    break;
+                }
+    }
+    if (live && outside) rows_out[atomicAdd(count, 1u)] = (int32_t)i;
+}
+
+int launch_extreme_rows(pccm_ctx *ctx, const double *x64, int64_t n, const float *dirs, int ndirs, unsigned long long *best)
+{
+    ProfScope ps(ctx, PCCM_K_POINT);
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_extreme_rows, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, ctx->stream, x64, n, dirs, ndirs, best);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+int launch_outside_planes(pccm_ctx *ctx, const double *x64, int64_t n, const double *planes, int nplanes, double margin,
+                          int32_t *rows_out, unsigned int *count)
+{
+    ProfScope ps(ctx, PCCM_K_POINT);
+    hipLaunchKernelGGL(k_outside_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x64, n, planes, nplanes, margin,
+                       rows_out, count);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+}  // namespace pccm

@@ -65,6 +65,14 @@ class OracleEngine:
         return scale * (_signed_rows(own, zeros, np.zeros(len(own), np.int64), scheme)
                         - _signed_rows(other[rows], zeros, np.zeros(len(rows), np.int64), scheme))
 
+    def extreme_rows(self, which, directions):
+        return np.argmax(self.pts[which] @ np.asarray(directions, dtype=np.float64).T, axis=0).astype(np.int32)
+
+    def rows_outside(self, which, planes, margin):
+        p = np.asarray(planes, dtype=np.float64)
+        val = self.pts[which] @ p[:, :3].T + p[:, 3]
+        return np.nonzero(np.any(val > -margin, axis=1))[0].astype(np.int32)
+
     def obb_frames(self, hull_vertices, hull_triangles):
         best_vol, best_ext = np.inf, None
         for a, b, c in np.asarray(hull_triangles, dtype=np.float64):

@@ -25,6 +25,25 @@ def test_oracle_finds_the_box_of_a_rotated_cuboid(dims):
     assert np.allclose(np.sort(ext), np.sort(dims), rtol=1e-9)
 
 
+def test_thinning_keeps_every_hull_vertex():
+    """hull_candidates (extreme points -> inner polytope -> points not strictly inside) must not lose a hull vertex."""
+    from scipy.spatial import ConvexHull
+    from open_pcc_metric_amd import extent as ext_mod
+    rng = np.random.default_rng(11)
+    shapes = [rng.standard_normal((30000, 3)) * [3.0, 1.0, 0.5],                       # blob
+              np.unique(np.round(rng.standard_normal((60000, 3)) * [30.0, 12.0, 6.0]), axis=0),   # voxelised, coplanar facets
+              rotated_box(25000, (1.0, 2.0, 3.0), 12)]
+    for pts in shapes:
+        eng = OracleEngine()
+        eng.set_cloud(0, pts)
+        keep = ext_mod.hull_candidates(pts, eng)
+        assert len(keep) < len(pts) // 2                                               # it does thin
+        full = ConvexHull(pts)
+        assert set(full.vertices.tolist()) <= set(keep.tolist())
+        thin = ConvexHull(pts[keep])
+        assert np.isclose(thin.volume, full.volume, rtol=1e-12)
+
+
 def test_host_plumbing_uses_the_engine():
     pts = rotated_box(300, (1.0, 2.0, 3.0), 2)
     eng = OracleEngine()
@@ -68,3 +87,31 @@ def test_gpu_get_extent_through_cloud_pair_and_degenerate_hull():
     with pytest.raises(ValueError):
         e.obb_frames(np.eye(3), tri)
     e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_thinning_keeps_every_hull_vertex_and_the_extent():
+    from scipy.spatial import ConvexHull
+    from open_pcc_metric_amd import _native as nat
+    from open_pcc_metric_amd import extent as ext_mod
+    rng = np.random.default_rng(13)
+    def shell(n, c, r):
+        v = rng.standard_normal((n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return np.asarray(c) + v * np.asarray(r)
+    figure = np.unique(np.round(np.vstack([shell(60000, [512, 512, 700], [90, 60, 110]), shell(60000, [512, 512, 450], [130, 80, 200]),
+                                           shell(30000, [420, 512, 200], [50, 50, 220]), shell(30000, [600, 512, 200], [50, 50, 220])])), axis=0)
+    for pts in (figure, rng.standard_normal((50000, 3)) * [3.0, 1.0, 0.5]):
+        e = nat.Engine(0)
+        e.set_cloud(0, pts)
+        e.set_cloud(1, pts[:10])
+        keep = ext_mod.hull_candidates(pts, e)
+        full = ConvexHull(pts)
+        assert len(keep) < len(pts) // 3
+        assert set(full.vertices.tolist()) <= set(keep.tolist())
+        got = minimal_obb_extent(pts, e)
+        e.close()
+        # same hull either way; the frames, though, hang on how Qhull triangulates coplanar facets, which depends on its
+        # input set and order -- so the search is compared on the very point set the product hands to Qhull
+        assert np.isclose(ConvexHull(pts[keep]).volume, full.volume, rtol=1e-12)
+        want = orc.minimal_obb_extent(pts[keep])
+        assert np.isclose(np.prod(got), np.prod(want), rtol=1e-12) and np.allclose(np.sort(got), np.sort(want), rtol=1e-9)
