@@ -872,20 +872,35 @@ static int measure_occupancy(pccm_ctx *ctx, const Cloud &c, double scale, Occupa
     return PCCM_OK;
 }
 
-// shrink the cell edge until the occupied cells hold ~2 ppc points (or the cell budget binds)
+// Shrink the cell edge until the cells are no longer crowded (or the cell budget binds).  Two measures, both taken
+// over the larger cloud: points per OCCUPIED cell (surfaces leave most of a volume-rule grid empty and pile their
+// points into the rest) and the size-biased mean sum(h^2)/sum(h) -- the population of the cell a random POINT sits in,
+// which is what a query pays for: scanner data is sparse far out and crowded near the sensor, so its plain mean
+// looks harmless (4) while the typical point shares its cell with 50 others.  A step that does not relieve the
+// crowding (duplicates: identical points cannot be separated) is taken back.
 static int fit_scale(pccm_ctx *ctx, const Cloud &c, double &scale, Occupancy &o)
 {
-    const double target = 2.0 * points_per_cell();
+    const double target = 2.0 * points_per_cell(), target_sb = 4.0 * points_per_cell();
+    auto crowding = [&](const Occupancy &q) { return fmax(q.mean / target, q.sb / target_sb); };
     scale = 1.0;
+    Occupancy prev;
+    double prev_scale = 1.0;
     for (int it = 0; it < 4; ++it) {
         int rc = measure_occupancy(ctx, c, scale, o);
         if (rc) return rc;
-        if (o.mean <= 1.5 * target) break;
+        if (it > 0 && crowding(o) > 0.8 * crowding(prev)) {      // no relief: keep the coarser (cheaper) grid
+            scale = prev_scale;
+            o = prev;
+            break;
+        }
+        if (crowding(o) <= 1.5) break;
         GridGeom g2;
         int64_t nc2;
-        const double next = scale * fmax(0.35, pow(target / o.mean, 1.0 / 2.4));
+        const double next = scale * fmax(0.35, pow(1.0 / crowding(o), 1.0 / 2.4));
         choose_geometry(ctx, g2, nc2, next);
         if (nc2 == o.ncells) break;                // cell budget or per-axis limit reached
+        prev = o;
+        prev_scale = scale;
         scale = next;
     }
     return PCCM_OK;
