@@ -685,8 +685,8 @@ static double points_per_cell()
 
 // Which query kernel?  (PCCM_GRID_COOP=0/1 forces one; default: decided per pair of clouds in decide_scale)
 // The cooperative kernel amortises its per-segment work (bounds, staging) over the queries of a wave that share an
-// x-row of cells; that pays when rows are well filled -- volumetric float data (1.5x over the per-thread kernel) and
-// crowded cells (LiDAR: 2x) -- and backfires when they are not: on surfaces a row holds a handful of points, a wave
+// x-row of cells; that pays when rows are well filled -- volumetric float data (1.5x over the per-thread kernel) --
+// and backfires when they are not: on surfaces a row holds a handful of points, a wave
 // walks a dozen segments with a few lanes active in each (sphere surface, 1M points: 0.83 ms vs 0.28 ms per-thread;
 // voxelised: 1.55 vs 0.33 ms), and on integer lattices its in-place tie resolution is no match for plain fp64
 // (128^3 lattice volume: 4.4 vs 0.22 ms).  Measured crossover for float data: ~40 points per x-row of the grid.
