@@ -201,6 +201,10 @@ int pccm_rows_outside(pccm_ctx *ctx, int which, const double *planes, int nplane
  * evaluated on the device without the dependent chain (csrc/pccm_color.hip). */
 int pccm_seq_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double out[3]);
 
+/* Host-only helper (no GPU) of the PCD reader that stands in for o3d.io.read_point_cloud (handler.py:57):
+ * liblzf decompression of a binary_compressed body.  *out_len = bytes written (<= out_cap). */
+int pccm_lzf_decompress(const unsigned char *in, int64_t in_len, unsigned char *out, int64_t out_cap, int64_t *out_len);
+
 /* Host-only helper (no GPU): rows of RGB in [n][3] -> the target scheme of transform_colors(),
  * metric.py:261-290 (scheme 1 = "ycc", 2 = "yuv"), bit-compatible with the reference's per-row np.matmul. */
 int pccm_color_transform(const double *rgb, int64_t n, int scheme, double *out);

@@ -32,7 +32,7 @@ SYMBOLS = (
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
     "pccm_set_colors", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
-    "pccm_color_transform", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
+    "pccm_color_transform", "pccm_lzf_decompress", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
 )
@@ -95,6 +95,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_sync.argtypes = [vp]
     lib.pccm_drop_caches.argtypes = [vp]
     lib.pccm_color_transform.argtypes = [vp, i64, i32, vp]
+    lib.pccm_lzf_decompress.argtypes = [vp, i64, vp, i64, ctypes.POINTER(i64)]
     lib.pccm_set_colors.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_color_reduce.argtypes = [vp, i32, i32, ctypes.c_double, vp, i64, dp, dp]
     lib.pccm_seq_colsum.argtypes = [vp, vp, i64, dp]
@@ -160,6 +161,14 @@ def color_transform(colors: np.ndarray, scheme: str) -> np.ndarray:
     _check(load().pccm_color_transform(src.ctypes.data_as(ctypes.c_void_p), src.shape[0], {"ycc": 1, "yuv": 2}[scheme],
                                        out.ctypes.data_as(ctypes.c_void_p)))
     return out
+
+
+def lzf_decompress(data: bytes, size: int) -> bytes:
+    """liblzf decompression (host helper of libpccm; PCD binary_compressed bodies)."""
+    out = ctypes.create_string_buffer(max(1, int(size)))
+    got = ctypes.c_int64()
+    _check(load().pccm_lzf_decompress(ctypes.c_char_p(bytes(data)), len(data), out, int(size), ctypes.byref(got)))
+    return out.raw[:got.value]
 
 
 def _as_rows(a, what: str) -> Tuple[object, int, int, int, object]:

@@ -1056,6 +1056,39 @@ int pccm_color_transform(const double *rgb, int64_t n, int scheme, double *out)
     return PCCM_OK;
 }
 
+// Host helper for the PCD reader (io.py): liblzf decompression (binary_compressed bodies).  Format: a control byte c;
+// c < 32: c + 1 literal bytes follow; otherwise a back reference of length (c >> 5) + 2 (7 in the field: one more
+// length byte is added) at distance (((c & 31) << 8) | next byte) + 1.
+int pccm_lzf_decompress(const unsigned char *in, int64_t in_len, unsigned char *out, int64_t out_cap, int64_t *out_len)
+{
+    if (!in || !out || !out_len || in_len < 0 || out_cap < 0) return fail(PCCM_E_ARG, "bad argument");
+    int64_t ip = 0, op = 0;
+    while (ip < in_len) {
+        const unsigned c = in[ip++];
+        if (c < 32) {
+            const int64_t run = (int64_t)c + 1;
+            if (ip + run > in_len || op + run > out_cap) return fail(PCCM_E_ARG, "corrupt LZF stream (literal run)");
+            memcpy(out + op, in + ip, (size_t)run);
+            ip += run;
+            op += run;
+        } else {
+            int64_t len = c >> 5;
+            if (len == 7) {
+                if (ip >= in_len) return fail(PCCM_E_ARG, "corrupt LZF stream (length)");
+                len += in[ip++];
+            }
+            if (ip >= in_len) return fail(PCCM_E_ARG, "corrupt LZF stream (offset)");
+            const int64_t ref = op - ((int64_t)(c & 31) << 8) - in[ip++] - 1;
+            len += 2;
+            if (ref < 0 || op + len > out_cap) return fail(PCCM_E_ARG, "corrupt LZF stream (back reference)");
+            for (int64_t k = 0; k < len; ++k) out[op + k] = out[ref + k];      // may overlap: byte by byte
+            op += len;
+        }
+    }
+    *out_len = op;
+    return PCCM_OK;
+}
+
 int pccm_drop_caches(pccm_ctx *ctx)
 {
     CHECK_CTX(ctx);

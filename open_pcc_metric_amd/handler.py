@@ -8,7 +8,8 @@ Extra, optional flags (defaults reproduce the reference): ``--device``, ``--engi
 differ in size), ``--extent X Y Z`` (inject the PSNR peak box instead of the
 Qhull minimal-OBB restatement).  Files without normals get them estimated on the GPU when
 --point-to-plane asks for them (k = 30 covariance normals, as Open3D's estimate_normals does at
-cloud_pair.py:61-64).
+cloud_pair.py:61-64).  Input files: ply, pcd, xyz, xyzn, xyzrgb, pts (io.py; the formats
+``o3d.io.read_point_cloud`` picks by extension, handler.py:57).
 """
 import click
 

@@ -2,7 +2,8 @@
 
 PLY (ascii, binary_little_endian, binary_big_endian) with vertex properties ``x y z`` (any scalar
 type), optional ``nx ny nz`` and ``red green blue`` (uchar -> [0, 1] like Open3D; float colours are
-taken as they are), and whitespace-separated ``.xyz`` / ``.txt`` (x y z [nx ny nz]).  Coordinates are
+taken as they are); PCL's PCD (ascii, binary, binary_compressed; x y z, normal_*, packed rgb/rgba);
+whitespace-separated ``.xyz`` / ``.xyzn`` / ``.txt`` (x y z [nx ny nz]), ``.xyzrgb`` and ``.pts``.  Coordinates are
 returned as float64 -- Open3D holds ``Vector3d`` -- so a float PLY yields fp32-representable doubles.
 """
 from __future__ import annotations
@@ -97,13 +98,134 @@ def _read_xyz(path: str) -> PointCloud:
     return cloud
 
 
+def _read_xyzrgb(path: str) -> PointCloud:
+    """x y z r g b, colours already in [0, 1] (Open3D's .xyzrgb)."""
+    import pandas as pd
+    table = pd.read_csv(path, sep=r"\s+", header=None, comment="#", engine="c",
+                        float_precision="round_trip").to_numpy(dtype=np.float64)
+    if table.ndim != 2 or table.shape[1] < 6:
+        raise ValueError(f"{path}: expected six columns (x y z r g b)")
+    return PointCloud(np.ascontiguousarray(table[:, :3]), None, np.ascontiguousarray(table[:, 3:6]))
+
+
+def _read_pts(path: str) -> PointCloud:
+    """Leica PTS: a count line, then x y z [intensity [r g b]] with colours 0..255 (Open3D's .pts)."""
+    import pandas as pd
+    with open(path, "rb") as fh:
+        first = fh.readline().split()
+    skip = 1 if len(first) == 1 else 0
+    table = pd.read_csv(path, sep=r"\s+", header=None, skiprows=skip, engine="c",
+                        float_precision="round_trip").to_numpy(dtype=np.float64)
+    if table.ndim != 2 or table.shape[1] < 3:
+        raise ValueError(f"{path}: expected at least three columns")
+    if skip and int(first[0]) != table.shape[0]:
+        raise ValueError(f"{path}: header announces {int(first[0])} points, file holds {table.shape[0]}")
+    cloud = PointCloud(np.ascontiguousarray(table[:, :3]))
+    if table.shape[1] >= 7:
+        cloud.colors = np.ascontiguousarray(table[:, 4:7]) / 255.0
+    elif table.shape[1] == 6:
+        cloud.colors = np.ascontiguousarray(table[:, 3:6]) / 255.0
+    return cloud
+
+
+_PCD_TYPES = {("F", 4): "f4", ("F", 8): "f8", ("U", 1): "u1", ("U", 2): "u2", ("U", 4): "u4", ("U", 8): "u8",
+              ("I", 1): "i1", ("I", 2): "i2", ("I", 4): "i4", ("I", 8): "i8"}
+
+
+def _read_pcd(path: str) -> PointCloud:
+    """PCL's PCD v0.7: DATA ascii | binary | binary_compressed; fields x y z, optional normal_x normal_y normal_z and
+    rgb / rgba (packed 0x00RRGGBB in a float or uint32 -> [0, 1], as Open3D unpacks it)."""
+    with open(path, "rb") as fh:
+        meta = {}
+        while True:
+            line = fh.readline()
+            if not line:
+                raise ValueError(f"{path}: unterminated PCD header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0].startswith("#"):
+                continue
+            meta[tok[0].upper()] = tok[1:]
+            if tok[0].upper() == "DATA":
+                break
+        body = fh.read()
+    try:
+        names = meta["FIELDS"]
+        sizes = [int(s) for s in meta["SIZE"]]
+        types = meta["TYPE"]
+        counts = [int(c) for c in meta.get("COUNT", ["1"] * len(names))]
+        n = int(meta["POINTS"][0]) if "POINTS" in meta else int(meta["WIDTH"][0]) * int(meta["HEIGHT"][0])
+        mode = meta["DATA"][0].lower()
+    except (KeyError, ValueError, IndexError) as exc:
+        raise ValueError(f"{path}: malformed PCD header") from exc
+    if not (len(names) == len(sizes) == len(types) == len(counts)):
+        raise ValueError(f"{path}: FIELDS / SIZE / TYPE / COUNT disagree")
+    fields = []
+    for name, size, typ, count in zip(names, sizes, types, counts):
+        code = _PCD_TYPES.get((typ.upper(), size))
+        if code is None:
+            raise ValueError(f"{path}: unsupported PCD field type {typ}{size}")
+        for k in range(count):
+            fields.append((name if count == 1 else f"{name}_{k}", "<" + code))
+    dtype = np.dtype(fields)
+    if mode == "ascii":
+        import pandas as pd
+        if n == 0:
+            raise ValueError(f"{path}: empty cloud")
+        import io as _io
+        table = pd.read_csv(_io.BytesIO(body), sep=r"\s+", header=None, engine="c", float_precision="round_trip", nrows=n)
+        if table.shape[0] != n or table.shape[1] != len(fields):
+            raise ValueError(f"{path}: expected {n} rows of {len(fields)} values")
+        cols = {}
+        for j, (name, code) in enumerate(fields):
+            raw = table.iloc[:, j].to_numpy()
+            # a packed colour written as an integer must not pass through a float column
+            cols[name] = raw.astype(np.dtype(code)) if np.dtype(code).kind != "f" or raw.dtype.kind == "f" else raw.astype(np.float64).astype(np.dtype(code))
+    elif mode == "binary":
+        if len(body) < n * dtype.itemsize:
+            raise ValueError(f"{path}: truncated PCD body")
+        rec = np.frombuffer(body, dtype=dtype, count=n)
+        cols = {name: rec[name] for name, _ in fields}
+    elif mode == "binary_compressed":
+        if len(body) < 8:
+            raise ValueError(f"{path}: truncated PCD body")
+        clen, ulen = np.frombuffer(body, dtype="<u4", count=2)
+        from . import _native
+        raw = _native.lzf_decompress(body[8:8 + int(clen)], int(ulen))
+        if len(raw) != n * dtype.itemsize:
+            raise ValueError(f"{path}: compressed body has {len(raw)} bytes, header asks for {n * dtype.itemsize}")
+        cols, off = {}, 0
+        for name, code in fields:                       # the compressed layout is field by field
+            width = np.dtype(code).itemsize
+            cols[name] = np.frombuffer(raw, dtype=code, count=n, offset=off)
+            off += width * n
+    else:
+        raise ValueError(f"{path}: unknown PCD DATA mode {mode!r}")
+    if not all(k in cols for k in ("x", "y", "z")):
+        raise ValueError(f"{path}: no x y z fields")
+    cloud = PointCloud(np.stack([cols[k].astype(np.float64) for k in ("x", "y", "z")], axis=1))
+    if all(k in cols for k in ("normal_x", "normal_y", "normal_z")):
+        cloud.normals = np.stack([cols[k].astype(np.float64) for k in ("normal_x", "normal_y", "normal_z")], axis=1)
+    packed = cols.get("rgb", cols.get("rgba"))
+    if packed is not None:
+        bits = np.ascontiguousarray(packed).view(np.uint32) if packed.dtype.itemsize == 4 else packed.astype(np.uint32)
+        cloud.colors = np.stack([(bits >> 16) & 255, (bits >> 8) & 255, bits & 255], axis=1).astype(np.float64) / 255.0
+    return cloud
+
+
 def read_point_cloud(path: str) -> PointCloud:
+    """What ``o3d.io.read_point_cloud(path)`` yields for the formats Open3D picks by extension."""
     low = str(path).lower()
     if low.endswith(".ply"):
         return _read_ply(path)
+    if low.endswith(".pcd"):
+        return _read_pcd(path)
+    if low.endswith(".xyzrgb"):
+        return _read_xyzrgb(path)
+    if low.endswith(".pts"):
+        return _read_pts(path)
     if low.endswith((".xyz", ".xyzn", ".txt")):
         return _read_xyz(path)
-    raise ValueError(f"{path}: unsupported point cloud format (PLY and XYZ are)")
+    raise ValueError(f"{path}: unsupported point cloud format (ply, pcd, xyz, xyzn, xyzrgb, pts are)")
 
 
 def write_point_cloud(path: str, cloud, *, binary: bool = True, coord_dtype: str = "double") -> None:

@@ -50,3 +50,29 @@ def test_cli_color_rows(tmp_path):
     out = CliRunner().invoke(cli, ["--ocloud", pa, "--pcloud", pb, "--color", "ycc", "--extent", "1.0", "0.9", "0.8"])
     assert out.exit_code == 0, out.output
     assert out.output == g["meta"]["texts"]["cycc"]["string"] + "\n"
+
+
+def test_cli_reads_pcd_like_ply(tmp_path):
+    g = load_golden("uniform_1000")
+    pa, pb = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
+    write_point_cloud(pa, PointCloud(g["a"], g["na"]), coord_dtype="float")
+    write_point_cloud(pb, PointCloud(g["b"], g["nb"]), coord_dtype="float")
+
+    def pcd(path, pts, nrm):
+        rec = np.empty(len(pts), dtype=np.dtype([(k, "<f4") for k in ("x", "y", "z", "normal_x", "normal_y", "normal_z")]))
+        for k, col in zip(rec.dtype.names, np.hstack([pts, nrm]).T):
+            rec[k] = col
+        head = ("VERSION 0.7\nFIELDS x y z normal_x normal_y normal_z\nSIZE 4 4 4 4 4 4\nTYPE F F F F F F\nCOUNT 1 1 1 1 1 1\n"
+                f"WIDTH {len(pts)}\nHEIGHT 1\nPOINTS {len(pts)}\nDATA binary\n").encode()
+        with open(path, "wb") as fh:
+            fh.write(head + rec.tobytes())
+
+    qa, qb = str(tmp_path / "a.pcd"), str(tmp_path / "b.pcd")
+    pcd(qa, g["a"], g["na"])
+    pcd(qb, g["b"], g["nb"])
+    args = ["--hausdorff", "--point-to-plane", "--extent", "1", "0.9", "0.8"]
+    with np.errstate(divide="ignore"):
+        ply = CliRunner().invoke(cli, ["--ocloud", pa, "--pcloud", pb] + args)
+        pcd_out = CliRunner().invoke(cli, ["--ocloud", qa, "--pcloud", qb] + args)
+    assert ply.exit_code == 0 and pcd_out.exit_code == 0, pcd_out.output
+    assert ply.output == pcd_out.output

@@ -134,3 +134,104 @@ def test_colour_device_rows_materialise_like_numpy():
     assert same_bits(np.mean(diff ** 2, axis=0), np.mean(want ** 2, axis=0))
     assert same_bits(np.max((255 * diff) ** 2, axis=0), np.max((255 * want) ** 2, axis=0))
     assert same_bits(np.sum(diff ** 2), np.sum(want ** 2))       # not fused: materialises
+
+
+# ---- PCD / xyzrgb / pts (the other formats o3d.io.read_point_cloud picks by extension) -----------------------------
+def _lzf_literals(data: bytes) -> bytes:
+    """A valid (if useless) LZF stream: literal runs only."""
+    out = bytearray()
+    for i in range(0, len(data), 32):
+        chunk = data[i:i + 32]
+        out.append(len(chunk) - 1)
+        out += chunk
+    return bytes(out)
+
+
+def test_lzf_decoder_handles_back_references():
+    # "abcabcabcabc!": literal "abc", then a back reference of length 9 at distance 3 (overlapping copy), then "!"
+    stream = bytes([2]) + b"abc" + bytes([(7 << 5) | 0, 0, 2]) + bytes([0]) + b"!"
+    assert nat.lzf_decompress(stream, 64) == b"abcabcabcabc!"
+    assert nat.lzf_decompress(_lzf_literals(bytes(range(200))), 200) == bytes(range(200))
+    with pytest.raises(ValueError):
+        nat.lzf_decompress(bytes([5, 1, 2]), 64)                       # literal run past the end
+    with pytest.raises(ValueError):
+        nat.lzf_decompress(bytes([(1 << 5) | 0, 9]), 64)               # reference before the start
+
+
+def _pcd(tmp_path, mode, pts, nrm, rgb, name="c.pcd"):
+    n = len(pts)
+    packed = ((rgb[:, 0].astype(np.uint32) << 16) | (rgb[:, 1].astype(np.uint32) << 8) | rgb[:, 2].astype(np.uint32))
+    rec = np.empty(n, dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("normal_x", "<f4"), ("normal_y", "<f4"),
+                                      ("normal_z", "<f4"), ("rgb", "<u4")]))
+    for k, col in zip(("x", "y", "z"), pts.T):
+        rec[k] = col
+    for k, col in zip(("normal_x", "normal_y", "normal_z"), nrm.T):
+        rec[k] = col
+    rec["rgb"] = packed
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z rgb\n"
+            "SIZE 4 4 4 4 4 4 4\nTYPE F F F F F F U\nCOUNT 1 1 1 1 1 1 1\n"
+            f"WIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA {mode}\n").encode()
+    path = tmp_path / name
+    if mode == "ascii":
+        rows = "\n".join(" ".join([repr(float(v)) for v in (r["x"], r["y"], r["z"], r["normal_x"], r["normal_y"], r["normal_z"])]
+                                  + [str(int(r["rgb"]))]) for r in rec)
+        path.write_bytes(head + rows.encode() + b"\n")
+    elif mode == "binary":
+        path.write_bytes(head + rec.tobytes())
+    else:
+        soa = b"".join(np.ascontiguousarray(rec[k]).tobytes() for k in rec.dtype.names)
+        comp = _lzf_literals(soa)
+        path.write_bytes(head + np.array([len(comp), len(soa)], dtype="<u4").tobytes() + comp)
+    return str(path)
+
+
+@pytest.mark.parametrize("mode", ["ascii", "binary", "binary_compressed"])
+def test_pcd_reader(tmp_path, mode):
+    rng = np.random.default_rng(5)
+    pts = rng.random((257, 3), dtype=np.float32)
+    nrm = rng.standard_normal((257, 3)).astype(np.float32)
+    rgb = rng.integers(0, 256, (257, 3))
+    cloud = read_point_cloud(_pcd(tmp_path, mode, pts, nrm, rgb))
+    assert np.array_equal(np.asarray(cloud.points), pts.astype(np.float64))
+    assert np.array_equal(np.asarray(cloud.normals), nrm.astype(np.float64))
+    assert np.array_equal(np.asarray(cloud.colors), rgb / 255.0)
+
+
+def test_pcd_float_packed_rgb_and_errors(tmp_path):
+    pts = np.array([[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]], dtype=np.float32)
+    packed = np.array([(10 << 16) | (20 << 8) | 30, (255 << 16) | 7], dtype="<u4")
+    rec = np.empty(2, dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgb", "<f4")]))
+    rec["x"], rec["y"], rec["z"] = pts.T
+    rec["rgb"] = packed.view("<f4")                                     # PCL's classic float-packed colour
+    head = b"VERSION .7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA binary\n"
+    p = tmp_path / "f.pcd"
+    p.write_bytes(head + rec.tobytes())
+    cloud = read_point_cloud(str(p))
+    assert np.array_equal(np.asarray(cloud.colors), np.array([[10, 20, 30], [255, 0, 7]]) / 255.0)
+    assert not cloud.has_normals()
+    (tmp_path / "bad.pcd").write_bytes(head + rec.tobytes()[:10])
+    with pytest.raises(ValueError):
+        read_point_cloud(str(tmp_path / "bad.pcd"))
+    (tmp_path / "noxyz.pcd").write_bytes(b"FIELDS a b\nSIZE 4 4\nTYPE F F\nCOUNT 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n1 2\n")
+    with pytest.raises(ValueError):
+        read_point_cloud(str(tmp_path / "noxyz.pcd"))
+
+
+def test_xyzrgb_and_pts_readers(tmp_path):
+    rng = np.random.default_rng(6)
+    pts, col = rng.random((50, 3)), rng.random((50, 3))
+    a = tmp_path / "a.xyzrgb"
+    a.write_text("\n".join(" ".join(repr(float(v)) for v in row) for row in np.hstack([pts, col])) + "\n")
+    cloud = read_point_cloud(str(a))
+    assert np.array_equal(np.asarray(cloud.points), pts) and np.array_equal(np.asarray(cloud.colors), col)
+    rgb = rng.integers(0, 256, (50, 3))
+    b = tmp_path / "b.pts"
+    b.write_text("50\n" + "\n".join(" ".join([repr(float(v)) for v in p] + ["-1000"] + [str(int(c)) for c in k])
+                                      for p, k in zip(pts, rgb)) + "\n")
+    cloud = read_point_cloud(str(b))
+    assert np.array_equal(np.asarray(cloud.points), pts) and np.array_equal(np.asarray(cloud.colors), rgb / 255.0)
+    (tmp_path / "short.pts").write_text("3\n0 0 0\n1 1 1\n")
+    with pytest.raises(ValueError):
+        read_point_cloud(str(tmp_path / "short.pts"))
+    with pytest.raises(ValueError):
+        read_point_cloud(str(tmp_path / "cloud.obj"))
