@@ -980,6 +980,24 @@ static int decide_scale(pccm_ctx *ctx, uint64_t key)
     }
     const int big = ctx->cloud[1].n > ctx->cloud[0].n ? 1 : 0;
     const Cloud &c = ctx->cloud[big];
+    // The frames of a sequence -- or the decoded versions of one frame -- look alike: same point counts, same
+    // bounding box, same kind of coordinates.  The decisions below only steer speed, never results, so a pair that
+    // matches the previous one in all of that simply inherits them (0.3-0.7 ms of histogram passes and host round
+    // trips saved per fresh pair); anything unusual about the previous pair (trimmed box, brute engine) or any
+    // visible change makes the pair decide for itself.
+    PairSignature sig;
+    for (int k = 0; k < 2; ++k) {
+        const Cloud &q = ctx->cloud[k];
+        sig.n[k] = q.n;
+        sig.flags[k] = (q.exact32 ? 1 : 0) | (q.all_int ? 2 : 0);
+        for (int a = 0; a < 3; ++a) { sig.lo[k][a] = q.bb_min[a]; sig.hi[k][a] = q.bb_max[a]; }
+    }
+    if (gr.scale_key != 0 && !gr.boxed && !gr.hostile && sig.resembles(gr.sig) && !getenv("PCCM_GRID_NO_REUSE")) {
+        gr.scale_key = key;
+        gr.iso_key = key;                              // the isolation verdict (not hostile) is inherited too
+        return PCCM_OK;                                // gr.sig stays that of the pair that decided: no drift
+    }
+    gr.sig = sig;
     gr.boxed = false;
     gr.hostile = false;
     double scale = 1.0;

@@ -61,6 +61,26 @@ struct GridRec {          // 32 B: fp64 position + original row
     int32_t idx, pad;
 };
 
+struct PairSignature {           // what decide_scale looks at to tell "a pair like the last one"
+    int64_t n[2] = {0, 0};
+    int flags[2] = {0, 0};         // exact32 | all_int << 1
+    double lo[2][3] = {{0, 0, 0}, {0, 0, 0}}, hi[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    bool resembles(const PairSignature &o) const
+    {
+        for (int k = 0; k < 2; ++k) {
+            if (flags[k] != o.flags[k]) return false;
+            const double dn = (double)(n[k] - o.n[k]);
+            if (dn > 0.02 * (double)o.n[k] || -dn > 0.02 * (double)o.n[k]) return false;
+            for (int a = 0; a < 3; ++a) {
+                const double ext = o.hi[k][a] - o.lo[k][a], tol = 0.02 * ext;
+                const double d0 = lo[k][a] - o.lo[k][a], d1 = hi[k][a] - o.hi[k][a];
+                if (!(d0 <= tol && -d0 <= tol && d1 <= tol && -d1 <= tol)) return false;
+            }
+        }
+        return true;
+    }
+};
+
 struct Grid {                    // one geometry, both clouds (grid engine)
     uint64_t key = 0;              // derived from both Cloud::version values (0 = none)
     uint64_t scale_key = 0;        // clouds the cell-edge scale below was decided for
@@ -70,6 +90,7 @@ struct Grid {                    // one geometry, both clouds (grid engine)
     bool hostile = false;          // even so the cells are too crowded: PCCM_ENGINE_AUTO uses the brute engine
     bool coop = true;              // cooperative ring-1 kernel (well-filled x-rows) or the per-thread search (surfaces, lattices)
     double sb = 0.0;               // size-biased points per cell the decision saw
+    PairSignature sig;             // of the pair the decisions were last taken (or inherited) for
     uint64_t iso_key = 0;          // pair the isolation count below was taken for
     int64_t isolated[2] = {0, 0};  // points of cloud k with nothing of the other cloud within kMaxRing cells
     int dim[3] = {1, 1, 1};

@@ -215,3 +215,28 @@ def test_graph_replay_on_a_pair_that_takes_the_brute_engine():
         for k in want:
             assert np.array_equal(np.float64(got[k]), np.float64(want[k])), k
         pair.recompute()
+
+
+def test_inherited_decisions_never_change_results(engine):
+    """A pair that looks like the previous one (point counts, bounding boxes, coordinate kind) inherits its grid
+    decisions; if the look deceives -- same box, utterly different content -- only speed may suffer."""
+    n = 30000
+    rng = np.random.default_rng(21)
+    corners = np.array([[x, y, z] for x in (0.0, 1.0) for y in (0.0, 1.0) for z in (0.0, 1.0)])
+
+    def boxed(p):
+        p = p.astype(np.float32).astype(np.float64)
+        p[:8] = corners
+        return p
+
+    uniform = lambda: boxed(rng.random((n, 3)))
+    clumps = lambda: boxed(0.5 + 0.001 * rng.standard_normal((n, 3)))
+    halves = lambda lo: boxed(np.column_stack([lo + 0.4 * rng.random(n), rng.random(n), rng.random(n)]))
+    pairs = [(uniform(), uniform()), (clumps(), clumps()), (halves(0.0), halves(0.6)), (uniform(), clumps())]
+    for a, b in pairs:
+        engine.set_cloud(0, a); engine.set_cloud(1, b)
+        engine.nn_pair("auto")
+        for d, (q, r) in enumerate(((a, b), (b, a))):
+            idx, d2 = engine.fetch_nn(d)
+            oi, od = orc.nn(q, r, method="kdtree")
+            assert np.array_equal(d2, od) and np.array_equal(idx, oi)
