@@ -90,6 +90,10 @@ int pccm_device_count(int *n);
  * non-blocking stream) or a hipStream_t the caller owns (e.g. torch's current stream). */
 int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out);
 int pccm_ctx_destroy(pccm_ctx *ctx);
+/* Back to the state after pccm_ctx_create -- no clouds, shard 0 of 1, no graphs, profiling off -- but with every
+ * device allocation (and the grid decisions a look-alike pair may inherit) kept: for callers that run one pair
+ * after the other through the same context instead of paying context teardown and fresh allocations per pair. */
+int pccm_ctx_reset(pccm_ctx *ctx);
 
 /* Replaces CloudPair.__init__'s capture of the two clouds, cloud_pair.py:54-59.
  * Coordinates must be finite with |x| <= 1e15.  Invalidates earlier nn results. */

@@ -27,7 +27,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (
-    "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy",
+    "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
     "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
@@ -73,6 +73,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_device_count.argtypes = [ctypes.POINTER(i32)]
     lib.pccm_ctx_create.argtypes = [i32, vp, ctypes.POINTER(vp)]
     lib.pccm_ctx_destroy.argtypes = [vp]
+    lib.pccm_ctx_reset.argtypes = [vp]
     lib.pccm_set_cloud.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_set_normals.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_set_shard.argtypes = [vp, i32, i32]
@@ -171,6 +172,47 @@ def lzf_decompress(data: bytes, size: int) -> bytes:
     return out.raw[:got.value]
 
 
+# ---- engine pool ------------------------------------------------------------------------------------------------
+# Creating a context is cheap, tearing one down is not (4 ms of hipFree for a 1M-point pair) and a fresh one starts
+# with cold allocations (+0.8 ms) and no grid decisions to inherit.  CloudPair therefore borrows its engine here and
+# hands it back when it dies; a caller that evaluates one pair after the other pays the work, not the lifecycle.
+_POOL: dict = {}
+_POOL_MAX = 2
+
+
+def acquire_engine(device: int = 0) -> "Engine":
+    pool = _POOL.get(int(device))
+    while pool:
+        eng = pool.pop()
+        try:
+            eng.reset()
+            return eng
+        except Exception:                      # noqa: BLE001 -- a context that cannot be reset is not worth keeping
+            eng.close()
+    return Engine(device)
+
+
+def release_engine(eng: "Engine") -> None:
+    if not getattr(eng, "_ctx", None) or not eng._ctx.value:
+        return                                 # closed by hand
+    pool = _POOL.setdefault(eng.device, [])
+    if len(pool) < _POOL_MAX and eng not in pool:
+        pool.append(eng)
+    elif eng not in pool:
+        eng.close()
+
+
+def drain_pool() -> None:
+    for pool in _POOL.values():
+        while pool:
+            pool.pop().close()
+
+
+import atexit  # noqa: E402
+
+atexit.register(drain_pool)
+
+
 def _as_rows(a, what: str) -> Tuple[object, int, int, int, object]:
     """-> (pointer, n, dtype code, on_device, keepalive) for an (N, 3) f32/f64 array or CUDA tensor."""
     if hasattr(a, "is_cuda") and hasattr(a, "data_ptr"):      # torch tensor
@@ -215,6 +257,11 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def reset(self) -> None:
+        """Forget clouds, shard, graphs and profile; keep the device allocations (pccm_ctx_reset)."""
+        _check(self._lib.pccm_ctx_reset(self._ctx))
+        self._n = [0, 0]
 
     # -- inputs ---------------------------------------------------------------------------
     def set_cloud(self, which: int, points) -> None:

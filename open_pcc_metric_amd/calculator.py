@@ -67,6 +67,29 @@ class MetricCalculator:
         self._calculated_metrics[key] = metric
         return metric
 
+    def _visit(self, metric, program, planned, wanted):
+        """Post-order walk below ``metric`` (a method, not a closure: a recursive closure is a reference cycle that
+        would keep the calculator -- and with it the CloudPair and its GPU context -- alive until the cyclic GC runs)."""
+        key = metric._key()
+        known = self._calculated_metrics.get(key) or planned.get(key)
+        if known is not None:
+            return known
+        role = getattr(metric, "_pccm_role", 0) or (1 if isinstance(metric, PrimaryMetric) else
+                                                    2 if isinstance(metric, SecondaryMetric) else 0)
+        if role == 1:
+            if isinstance(metric, BoundarySqrtDistances):
+                wanted.append("boundary")
+            program.append((metric, None))
+        elif role == 2:
+            if isinstance(metric, EuclideanDistance):
+                wanted.append((metric.is_left, metric.point_to_plane))
+            resolved = {name: self._visit(dep, program, planned, wanted) for name, dep in metric._get_dependencies().items()}
+            program.append((metric, resolved))
+        else:
+            raise RuntimeError(f"Metric of unknown AbstractMetric subclass {type(metric).__name__}")
+        planned[key] = metric
+        return metric
+
     def _plan(self, metrics_list: typing.List[AbstractMetric]):
         """Resolve the dependency DAG of the request WITHOUT evaluating anything.
 
@@ -77,29 +100,7 @@ class MetricCalculator:
         ``use_graph``, already running -- while this Python bookkeeping happens; the blocking part of a
         report is then only the ``calculate()`` calls themselves."""
         program, planned, wanted = [], {}, []
-
-        def visit(metric):
-            key = metric._key()
-            known = self._calculated_metrics.get(key) or planned.get(key)
-            if known is not None:
-                return known
-            role = getattr(metric, "_pccm_role", 0) or (1 if isinstance(metric, PrimaryMetric) else
-                                                        2 if isinstance(metric, SecondaryMetric) else 0)
-            if role == 1:
-                if isinstance(metric, BoundarySqrtDistances):
-                    wanted.append("boundary")
-                program.append((metric, None))
-            elif role == 2:
-                if isinstance(metric, EuclideanDistance):
-                    wanted.append((metric.is_left, metric.point_to_plane))
-                resolved = {name: visit(dep) for name, dep in metric._get_dependencies().items()}
-                program.append((metric, resolved))
-            else:
-                raise RuntimeError(f"Metric of unknown AbstractMetric subclass {type(metric).__name__}")
-            planned[key] = metric
-            return metric
-
-        requested = [visit(m) for m in metrics_list]
+        requested = [self._visit(m, program, planned, wanted) for m in metrics_list]
         prefetch = getattr(self._cloud_pair, "prefetch_reductions", None)
         if prefetch is not None and wanted:
             prefetch(sorted(set(wanted), key=str))

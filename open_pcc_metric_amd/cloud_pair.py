@@ -258,10 +258,12 @@ class CloudPair:
         self._last_wanted = None
         self._extent = None if extent is None else np.asarray(extent, dtype=np.float64)
         self._coll = Collective(group)
+        self._owns_engine = False
         if _engine is None:
             if device is None:
                 device = int(os.environ.get("LOCAL_RANK", "0")) if self._coll.sharded else 0
-            _engine = nat.Engine(device)          # raises without libpccm.so or without a GPU
+            _engine = nat.acquire_engine(device)  # raises without libpccm.so or without a GPU; pooled contexts are reused
+            self._owns_engine = True
             self._coll.device = device            # the nccl exchange is staged on the same GPU
         self._engine = _engine
         for k, cloud in enumerate(self.clouds):
@@ -271,6 +273,24 @@ class CloudPair:
         if self._coll.sharded:
             _engine.set_shard(self._coll.rank, self._coll.world)
         self.recompute()
+
+    def close(self) -> None:
+        """Hand the GPU context back (it is reused by the next pair); the pair must not be used afterwards."""
+        eng = self.__dict__.pop("_engine", None)
+        if eng is not None and self.__dict__.get("_owns_engine"):
+            nat.release_engine(eng)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def recompute(self) -> None:
         """Run both directional sweeps again on the clouds already resident in HBM

@@ -42,6 +42,19 @@ int ensure(pccm_ctx *ctx, DevBuf &b, size_t bytes)
     return PCCM_OK;
 }
 
+int grow(void **p, size_t &cap, size_t bytes)
+{
+    if (*p && cap >= bytes) return PCCM_OK;
+    if (*p) {
+        (void)hipFree(*p);
+        *p = nullptr;
+        cap = 0;
+    }
+    PCCM_HIP(hipMalloc(p, bytes ? bytes : 1));
+    cap = bytes;
+    return PCCM_OK;
+}
+
 static hipEvent_t take_event(pccm_ctx *ctx)
 {
     if (!ctx->event_pool.empty()) {
@@ -105,8 +118,12 @@ static void free_cloud(Cloud &c)
     c.xyz64 = nullptr;
     c.nrm64 = nullptr;
     c.rgb64 = nullptr;
+    c.cap32 = c.cap64 = c.cap_nrm = c.cap_rgb = 0;
     c.n = c.n_pad = c.n_nrm = c.n_rgb = 0;
 }
+
+// forget the content, keep the allocations
+static void drop_cloud(Cloud &c) { c.n = c.n_pad = c.n_nrm = c.n_rgb = 0; }
 
 static void free_nn(NNResult &r)
 {
@@ -267,16 +284,17 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     if (dtype != PCCM_F32 && dtype != PCCM_F64) return fail(PCCM_E_ARG, "dtype must be PCCM_F32 or PCCM_F64");
     Cloud &c = ctx->cloud[which];
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    free_cloud(c);
+    drop_cloud(c);                                   // its normals and colours go with it
     for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
     ctx->epoch++;
     c.version++;
     const int64_t n_pad = (n + kScanTile - 1) / kScanTile * kScanTile;
-    PCCM_HIP(hipMalloc((void **)&c.xyz32, (size_t)n_pad * 3 * sizeof(float)));
-    PCCM_HIP(hipMalloc((void **)&c.xyz64, (size_t)n * 3 * sizeof(double)));
+    int rc = grow((void **)&c.xyz32, c.cap32, (size_t)n_pad * 3 * sizeof(float));
+    if (!rc) rc = grow((void **)&c.xyz64, c.cap64, (size_t)n * 3 * sizeof(double));
+    if (rc) return rc;
     const size_t esz = dtype == PCCM_F32 ? 4 : 8;
     const void *dsrc = nullptr;
-    int rc = upload(ctx, xyz, (size_t)n * 3 * esz, on_device, &dsrc);
+    rc = upload(ctx, xyz, (size_t)n * 3 * esz, on_device, &dsrc);
     if (rc) return rc;
     unsigned long long *stats = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(stats, 0, 10 * sizeof(unsigned long long), ctx->stream));
@@ -289,7 +307,7 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     double maxabs;
     memcpy(&maxabs, &h[0], sizeof(double));
     if (h[2] != 0 || !(maxabs <= kMaxAbsCoord)) {
-        free_cloud(c);
+        drop_cloud(c);
         return fail(PCCM_E_ARG, "cloud %d has non-finite coordinates or |x| > 1e15", which);
     }
     c.n = n;
@@ -321,15 +339,12 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     for (int d = 0; d < 3; ++d) ctx->nn_gen[d]++;      // pending D2 reductions used the old normals
     ctx->epoch++;
-    if (c.nrm64) {
-        PCCM_HIP(hipFree(c.nrm64));
-        c.nrm64 = nullptr;
-        c.n_nrm = 0;
-    }
-    PCCM_HIP(hipMalloc((void **)&c.nrm64, (size_t)n * 3 * sizeof(double)));
+    c.n_nrm = 0;
+    int rc = grow((void **)&c.nrm64, c.cap_nrm, (size_t)n * 3 * sizeof(double));
+    if (rc) return rc;
     const size_t esz = dtype == PCCM_F32 ? 4 : 8;
     const void *dsrc = nullptr;
-    int rc = upload(ctx, nrm, (size_t)n * 3 * esz, on_device, &dsrc);
+    rc = upload(ctx, nrm, (size_t)n * 3 * esz, on_device, &dsrc);
     if (rc) return rc;
     unsigned long long *stats = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
@@ -339,9 +354,7 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
     PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     if (h[2] != 0) {
-        (void)hipFree(c.nrm64);
-        c.nrm64 = nullptr;
-        return fail(PCCM_E_ARG, "normals of cloud %d are not finite", which);
+        return fail(PCCM_E_ARG, "normals of cloud %d are not finite", which);      // n_nrm stays 0: no normals
     }
     c.n_nrm = n;
     return PCCM_OK;
@@ -358,14 +371,11 @@ int pccm_set_colors(pccm_ctx *ctx, int which, const void *rgb, int64_t n, int dt
     if (c.n == 0) return fail(PCCM_E_STATE, "set cloud %d before its colours", which);
     if (n != c.n) return fail(PCCM_E_ARG, "cloud %d has %lld points but %lld colours", which, (long long)c.n, (long long)n);
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    if (c.rgb64) {
-        PCCM_HIP(hipFree(c.rgb64));
-        c.rgb64 = nullptr;
-        c.n_rgb = 0;
-    }
-    PCCM_HIP(hipMalloc((void **)&c.rgb64, (size_t)n * 3 * sizeof(double)));
+    c.n_rgb = 0;
+    int rc = grow((void **)&c.rgb64, c.cap_rgb, (size_t)n * 3 * sizeof(double));
+    if (rc) return rc;
     const void *dsrc = nullptr;
-    int rc = upload(ctx, rgb, (size_t)n * 3 * (dtype == PCCM_F32 ? 4 : 8), on_device, &dsrc);
+    rc = upload(ctx, rgb, (size_t)n * 3 * (dtype == PCCM_F32 ? 4 : 8), on_device, &dsrc);
     if (rc) return rc;
     unsigned long long *stats = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
@@ -383,7 +393,7 @@ static int color_operands(pccm_ctx *ctx, int dir, int scheme, const int32_t *row
     if (dir != PCCM_DIR_LEFT && dir != PCCM_DIR_RIGHT) return fail(PCCM_E_ARG, "colour metrics exist for directions 0 and 1");
     if (scheme < 0 || scheme > 2) return fail(PCCM_E_ARG, "unknown colour scheme %d", scheme);
     const Cloud &it = ctx->cloud[dir == PCCM_DIR_LEFT ? 0 : 1], &se = ctx->cloud[dir == PCCM_DIR_LEFT ? 1 : 0];
-    if (!it.rgb64 || !se.rgb64) return fail(PCCM_E_STATE, "both clouds need colours (pccm_set_colors)");
+    if (it.n_rgb <= 0 || se.n_rgb <= 0) return fail(PCCM_E_STATE, "both clouds need colours (pccm_set_colors)");
     if (rows) {
         if (nrows != it.n) return fail(PCCM_E_ARG, "%lld neighbour rows for %lld points", (long long)nrows, (long long)it.n);
         int rc = ensure(ctx, ctx->color_idx, (size_t)nrows * sizeof(int32_t));
@@ -563,7 +573,7 @@ int pccm_get_normals(pccm_ctx *ctx, int which, double *out)
     if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
     if (!out) return fail(PCCM_E_ARG, "null pointer");
     const Cloud &c = ctx->cloud[which];
-    if (!c.nrm64 || c.n_nrm <= 0) return fail(PCCM_E_STATE, "cloud %d has no normals", which);
+    if (c.n_nrm <= 0) return fail(PCCM_E_STATE, "cloud %d has no normals", which);
     PCCM_HIP(hipMemcpyAsync(out, c.nrm64, (size_t)c.n_nrm * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     return PCCM_OK;
@@ -721,7 +731,7 @@ static int check_normals(const Cloud &se, const NNResult &res, int normal_mode)
 {
     if (normal_mode != PCCM_NORMAL_ROW && normal_mode != PCCM_NORMAL_NEIGHBOUR)
         return fail(PCCM_E_ARG, "bad normal mode %d", normal_mode);
-    if (!se.nrm64) return fail(PCCM_E_STATE, "the searched cloud has no normals (pccm_set_normals)");
+    if (se.n_nrm <= 0) return fail(PCCM_E_STATE, "the searched cloud has no normals (pccm_set_normals)");
     if (normal_mode == PCCM_NORMAL_ROW && res.end > se.n_nrm)
         return fail(PCCM_E_RANGE, "index %lld is out of bounds for axis 0 with size %lld (row-indexed normals, reference quirk Q1)",
                     (long long)se.n_nrm, (long long)se.n_nrm);
@@ -1216,6 +1226,36 @@ int pccm_graph_destroy(pccm_ctx *ctx, int graph_id)
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     graph_free(ctx->graphs[graph_id]);
     return PCCM_OK;
+}
+
+int pccm_ctx_reset(pccm_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    if (ctx->capturing) {                              // an abandoned capture: end it, discard what it recorded
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(ctx->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        ctx->capturing = false;
+        ctx->capture_failed = false;
+        ctx->cap_ops.clear();
+    }
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 2; ++k) {
+        drop_cloud(ctx->cloud[k]);
+        ctx->cloud[k].version++;
+    }
+    ctx->rank = 0;
+    ctx->world = 1;
+    for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
+    for (auto &s : ctx->slots) s.pending = false;
+    for (auto &g : ctx->graphs) graph_free(g);
+    ctx->graphs.clear();
+    ctx->epoch++;
+    grid_invalidate(ctx);                              // the geometry decisions stay: the next pair may inherit them
+    int rc = collect_spans(ctx);
+    ctx->prof_on = false;
+    for (int k = 0; k < PCCM_K_COUNT; ++k) { ctx->prof_ms[k] = 0.0; ctx->prof_n[k] = 0; }
+    return rc;
 }
 
 int pccm_sync(pccm_ctx *ctx)

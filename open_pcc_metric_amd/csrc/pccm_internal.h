@@ -31,6 +31,9 @@ struct Cloud {
     int64_t n_nrm = 0;
     double *rgb64 = nullptr;    // [n_rgb][3] colours as the caller gave them (RGB in [0, 1])
     int64_t n_rgb = 0;
+    // allocations outlive their content (n / n_nrm / n_rgb say what is there): a context that serves one pair after
+    // the other -- the engine pool of _native.py -- does not pay hipFree + hipMalloc per cloud
+    size_t cap32 = 0, cap64 = 0, cap_nrm = 0, cap_rgb = 0;
     bool exact32 = true;        // every coordinate survives the fp64 -> fp32 -> fp64 round trip
     bool all_int = false;       // ... and is an integer (voxelised content: exact ties are the rule)
     double maxabs = 0.0;
@@ -176,6 +179,7 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 int ensure(pccm_ctx *ctx, DevBuf &b, size_t bytes);
+int grow(void **p, size_t &cap, size_t bytes);      // (re)allocate *p to hold `bytes`; keeps a buffer that is large enough
 
 struct ProfScope {   // records a HIP-event pair around a launch group when profiling is on
     pccm_ctx *ctx;

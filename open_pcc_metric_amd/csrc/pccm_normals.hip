@@ -428,11 +428,7 @@ int estimate_normals(pccm_ctx *ctx, int which, int k)
         g.slack[a] = (fabs(gr.org[a]) + (gr.dim[a] + 2) * gr.h[a]) * 0x1.0p-48;
     }
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    if (c.nrm64 && c.n_nrm != c.n) {
-        PCCM_HIP(hipFree(c.nrm64));
-        c.nrm64 = nullptr;
-    }
-    if (!c.nrm64) PCCM_HIP(hipMalloc((void **)&c.nrm64, (size_t)c.n * 3 * sizeof(double)));
+    if ((rc = grow((void **)&c.nrm64, c.cap_nrm, (size_t)c.n * 3 * sizeof(double)))) return rc;
     c.n_nrm = c.n;
     for (int d = 0; d < 3; ++d) ctx->nn_gen[d]++;      // pending D2 reductions would use stale normals
     ctx->epoch++;

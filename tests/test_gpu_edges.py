@@ -240,3 +240,26 @@ def test_inherited_decisions_never_change_results(engine):
             idx, d2 = engine.fetch_nn(d)
             oi, od = orc.nn(q, r, method="kdtree")
             assert np.array_equal(d2, od) and np.array_equal(idx, oi)
+
+
+def test_pooled_context_starts_clean():
+    """CloudPair borrows its context from a pool (_native.acquire_engine): whatever the previous pair left behind --
+    normals, colours, shard, graphs -- must be gone, and results must not depend on what ran before."""
+    rng = np.random.default_rng(31)
+    a, b = rng.random((5000, 3)), rng.random((5000, 3))
+    na, nb = rng.standard_normal((5000, 3)), rng.standard_normal((5000, 3))
+    opts = transform_options(CalculateOptions(None, True, True))
+    nat.drain_pool()
+    with CloudPair(PointCloud(a, na, a), PointCloud(b, nb, b), extent=[1, 1, 1], use_graph=True) as first:
+        want = MetricCalculator(first).calculate(opts).as_dict()
+        first.recompute(); first.recompute()                       # leaves a captured graph behind
+        ctx_id = first._engine._ctx.value
+    with CloudPair(PointCloud(a), PointCloud(b), extent=[1, 1, 1], estimate_normals=False) as bare:
+        assert bare._engine._ctx.value == ctx_id                   # the same context, reused
+        with pytest.raises(ValueError, match="normals"):           # ... without the first pair's normals
+            MetricCalculator(bare).calculate(transform_options(CalculateOptions(None, False, True)))
+        with pytest.raises(RuntimeError):                          # ... and without its colours
+            bare._engine.color_reduce(nat.DIR_LEFT, "rgb")
+    with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1]) as again:
+        got = MetricCalculator(again).calculate(opts).as_dict()
+    assert list(got) == list(want) and all(np.float64(got[k]) == np.float64(want[k]) for k in want)
