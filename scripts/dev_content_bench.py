@@ -24,7 +24,7 @@ for it in range(4):
     res = MetricCalculator(pair).calculate(transform_options(opts)).as_dict()
     t2 = time.perf_counter()
     print(f"run {it}: CloudPair (H2D, ingest, both sweeps) {1e3 * (t1 - t0):7.2f} ms | report (normals x2, self search, min-OBB, D1/D2/Hausdorff/colour) {1e3 * (t2 - t1):7.2f} ms")
-    pair._engine.close()
+    pair.close()
 import cProfile, pstats
 pair = CloudPair(PointCloud(a, None, ca), PointCloud(b, None, cb), normal_index="neighbour")
 pr = cProfile.Profile(); pr.enable()
