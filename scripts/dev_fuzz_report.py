@@ -71,7 +71,7 @@ while time.time() < t_end:
                 if not (same(mse, orc.color_mse(oc, rc, idx, scheme)) and same(hd, orc.color_hausdorff(oc, rc, idx, scheme))):
                     fails += 1
                     print(f"COLOUR MISMATCH it={it} seed={seed0} na={na} nb={nb} scheme={scheme} left={is_left}", flush=True)
-        pair._engine.close()
+        pair.close()
     except Exception as ex:                               # noqa: BLE001
         fails += 1
         print(f"ERROR it={it} seed={seed0} na={na} nb={nb} mode={mode}: {type(ex).__name__}: {ex}", flush=True)

@@ -86,4 +86,4 @@ def test_random_reports_match_the_oracle():
                     x, y = np.float64(got[k]), np.float64(want[k])
                     assert x == y or (np.isnan(x) and np.isnan(y)), (case, k, x, y)
                 pair.recompute()
-        pair._engine.close()
+        pair.close()
