@@ -75,6 +75,12 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     args = ap.parse_args()
 
+    lib = os.path.join(ROOT, "open_pcc_metric_amd", "csrc", "libpccm.so")
+    if not os.path.exists(lib) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        # a fresh checkout (built artefacts are git-ignored): build as __graft_entry__.build() does; the product itself
+        # never builds or falls back -- without the library it raises
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.dirname(lib), "-j4"], check=True, stdout=subprocess.DEVNULL)
     import torch
     import torch.distributed as dist
     from open_pcc_metric_amd import _native as nat
