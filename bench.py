@@ -81,6 +81,10 @@ def main():
         # never builds or falls back -- without the library it raises
         import subprocess
         subprocess.run(["make", "-s", "-C", os.path.dirname(lib), "-j4"], check=True, stdout=subprocess.DEVNULL)
+    for _ in range(600):                      # the other ranks of a multi-GPU launch wait for rank 0's build
+        if os.path.exists(lib):
+            break
+        time.sleep(0.5)
     import torch
     import torch.distributed as dist
     from open_pcc_metric_amd import _native as nat
