@@ -167,6 +167,10 @@ int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
  * replaces np.asarray(cloud.colors) behind get_left/right_colors(), cloud_pair.py:114-118. */
 int pccm_set_colors(pccm_ctx *ctx, int which, const void *rgb, int64_t n, int dtype, int on_device);
 
+/* The same from the uchar colours point-cloud files hold: rgb[n][3] bytes, widened on the device as k / 255.0 -- the
+ * division o3d.io.read_point_cloud (and io.py) perform on the host, bit for bit. */
+int pccm_set_colors_u8(pccm_ctx *ctx, int which, const unsigned char *rgb, int64_t n);
+
 /* Colour metrics of one direction on the device, metric.py:302-333 and :389-427.  Per row i of the
  * iterating cloud: own = T(rgb_own[i]), other = T(rgb_other[nn(i)]) (the gather of
  * get_left/right_neighbour_colors(), cloud_pair.py:120-124; T = transform_colors(), metric.py:261-290,

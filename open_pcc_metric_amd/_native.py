@@ -31,7 +31,7 @@ SYMBOLS = (
     "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
-    "pccm_set_colors", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
+    "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
     "pccm_color_transform", "pccm_lzf_decompress", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
     "pccm_profile_enable", "pccm_profile_reset", "pccm_profile_get", "pccm_nn_stats",
@@ -98,6 +98,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_color_transform.argtypes = [vp, i64, i32, vp]
     lib.pccm_lzf_decompress.argtypes = [vp, i64, vp, i64, ctypes.POINTER(i64)]
     lib.pccm_set_colors.argtypes = [vp, i32, vp, i64, i32, i32]
+    lib.pccm_set_colors_u8.argtypes = [vp, i32, vp, i64]
     lib.pccm_color_reduce.argtypes = [vp, i32, i32, ctypes.c_double, vp, i64, dp, dp]
     lib.pccm_seq_colsum.argtypes = [vp, vp, i64, dp]
     lib.pccm_obb_frames.argtypes = [vp, vp, i64, vp, i64, dp, dp]
@@ -276,6 +277,13 @@ class Engine:
     def set_colors(self, which: int, colors) -> None:
         ptr, n, dt, dev, keep = _as_rows(colors, "colors")
         _check(self._lib.pccm_set_colors(self._ctx, int(which), ptr, n, dt, dev))
+
+    def set_colors_u8(self, which: int, colors_u8) -> None:
+        """Colours as (N, 3) uint8; the device widens them as k / 255.0 (what the file readers do on the host)."""
+        c = np.ascontiguousarray(colors_u8, dtype=np.uint8)
+        if c.ndim != 2 or c.shape[1] != 3:
+            raise ValueError("colors_u8 must have shape (N, 3)")
+        _check(self._lib.pccm_set_colors_u8(self._ctx, int(which), c.ctypes.data_as(ctypes.c_void_p), c.shape[0]))
 
     @staticmethod
     def _rows_arg(rows):

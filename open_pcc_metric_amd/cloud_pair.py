@@ -452,7 +452,11 @@ class CloudPair:
     def _ensure_colours(self) -> None:
         if not self._colours_on_device:
             for k, cloud in enumerate(self.clouds):
-                self._engine.set_colors(k, _host_rows(cloud.colors))
+                u8 = getattr(cloud, "colors_u8", None)
+                if u8 is not None and hasattr(self._engine, "set_colors_u8"):
+                    self._engine.set_colors_u8(k, u8)        # file colours: 3 B/point up, the k / 255.0 redone on the device
+                else:
+                    self._engine.set_colors(k, _host_rows(cloud.colors))
             self._colours_on_device = True
 
     def _colour_rows_arg(self, direction: int):

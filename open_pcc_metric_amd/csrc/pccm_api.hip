@@ -386,6 +386,29 @@ int pccm_set_colors(pccm_ctx *ctx, int which, const void *rgb, int64_t n, int dt
     return PCCM_OK;
 }
 
+int pccm_set_colors_u8(pccm_ctx *ctx, int which, const unsigned char *rgb, int64_t n)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
+    if (!rgb || n <= 0) return fail(PCCM_E_ARG, "empty colours");
+    Cloud &c = ctx->cloud[which];
+    if (c.n == 0) return fail(PCCM_E_STATE, "set cloud %d before its colours", which);
+    if (n != c.n) return fail(PCCM_E_ARG, "cloud %d has %lld points but %lld colours", which, (long long)c.n, (long long)n);
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    c.n_rgb = 0;
+    int rc = grow((void **)&c.rgb64, c.cap_rgb, (size_t)n * 3 * sizeof(double));
+    if (rc) return rc;
+    const void *dsrc = nullptr;
+    rc = upload(ctx, rgb, (size_t)n * 3, 0, &dsrc);
+    if (rc) return rc;
+    rc = launch_colors_from_u8(ctx, (const unsigned char *)dsrc, n * 3, c.rgb64);
+    if (rc) return rc;
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    c.n_rgb = n;
+    return PCCM_OK;
+}
+
 // common front end of the two colour calls: operands of direction `dir` and the neighbour rows to use
 static int color_operands(pccm_ctx *ctx, int dir, int scheme, const int32_t *rows, int64_t nrows,
                           const Cloud **own, const Cloud **other, const int32_t **drows)

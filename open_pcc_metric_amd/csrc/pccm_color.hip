@@ -215,6 +215,22 @@ __global__ __launch_bounds__(kSumThreads) void k_color_colsum(const double *__re
     if (tid == 0) out[blockIdx.x] = s;
 }
 
+// uchar colours (what PLY / PCD / PTS files hold) widened on the device: k / 255.0, the very division the host readers
+// perform (IEEE, correctly rounded on both sides) -- 3 bytes per point over PCIe instead of 24
+__global__ __launch_bounds__(256) void k_colors_from_u8(const unsigned char *__restrict__ src, int64_t n3, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n3) out[i] = (double)src[i] / 255.0;
+}
+
+int launch_colors_from_u8(pccm_ctx *ctx, const unsigned char *src, int64_t n3, double *out)
+{
+    ProfScope ps(ctx, PCCM_K_INGEST);
+    hipLaunchKernelGGL(k_colors_from_u8, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, ctx->stream, src, n3, out);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
 int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, const int32_t *rows, int64_t n,
                       int64_t n_other, int scheme, double scale, int what, double *out,
                       unsigned long long *maxkeys, unsigned int *bad)

@@ -273,5 +273,6 @@ int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, con
                       int64_t n_other, int scheme, double scale, int what, double *out,
                       unsigned long long *maxkeys, unsigned int *bad);
 int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *out3);
+int launch_colors_from_u8(pccm_ctx *ctx, const unsigned char *src, int64_t n3, double *out);
 
 }  // namespace pccm

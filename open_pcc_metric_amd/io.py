@@ -80,9 +80,13 @@ def _read_ply(path: str) -> PointCloud:
     rgb = ("red", "green", "blue") if "red" in cols else ("r", "g", "b")
     if all(k in cols for k in rgb):
         colors = stack(rgb)
-        if raw_dtypes[rgb[0]].kind in "ui":
+        integral = raw_dtypes[rgb[0]].kind in "ui"
+        if integral:
+            raw = colors
             colors = colors / 255.0          # Open3D: uchar colours -> [0, 1]
         cloud.colors = colors
+        if integral and all(raw_dtypes[k] == np.dtype("u1") for k in rgb):
+            cloud.attach_colors_u8(raw)
     return cloud
 
 
@@ -208,7 +212,9 @@ def _read_pcd(path: str) -> PointCloud:
     packed = cols.get("rgb", cols.get("rgba"))
     if packed is not None:
         bits = np.ascontiguousarray(packed).view(np.uint32) if packed.dtype.itemsize == 4 else packed.astype(np.uint32)
-        cloud.colors = np.stack([(bits >> 16) & 255, (bits >> 8) & 255, bits & 255], axis=1).astype(np.float64) / 255.0
+        u8 = np.stack([(bits >> 16) & 255, (bits >> 8) & 255, bits & 255], axis=1).astype(np.uint8)
+        cloud.colors = u8.astype(np.float64) / 255.0
+        cloud.attach_colors_u8(u8)
     return cloud
 
 

@@ -32,7 +32,19 @@ class PointCloud:
 
     points = property(lambda self: self._points, lambda self, v: setattr(self, "_points", _rows(v, "points")))
     normals = property(lambda self: self._normals, lambda self, v: setattr(self, "_normals", _rows(v, "normals")))
-    colors = property(lambda self: self._colors, lambda self, v: setattr(self, "_colors", _rows(v, "colors")))
+    def _set_colors(self, v):
+        self._colors = _rows(v, "colors")
+        self.colors_u8 = None          # see attach_colors_u8
+
+    colors = property(lambda self: self._colors, _set_colors)
+
+    def attach_colors_u8(self, u8) -> None:
+        """The (N, 3) uint8 array ``colors`` was made from as ``u8 / 255.0`` (file readers call this): lets the GPU path
+        ship 3 bytes per point instead of 24 and redo the same division on the device.  Dropped when colors change."""
+        u8 = np.ascontiguousarray(u8, dtype=np.uint8)
+        if u8.shape != self._colors.shape:
+            raise ValueError("colors_u8 must match colors")
+        self.colors_u8 = u8
 
     def has_points(self) -> bool:
         return len(self._points) > 0

@@ -170,3 +170,20 @@ def test_colour_rows_override_and_errors(engine):
         engine.color_reduce(nat.DIR_LEFT, "ycc", rows=idx[:10])
     with pytest.raises(ValueError):
         engine.color_reduce(nat.DIR_SELF, "ycc")
+
+
+def test_uchar_colours_widen_on_the_device_like_on_the_host(engine):
+    a, b, _, _ = _coloured(5000, 12)
+    rng = np.random.default_rng(13)
+    ua, ub = rng.integers(0, 256, (5000, 3)).astype(np.uint8), rng.integers(0, 256, (5000, 3)).astype(np.uint8)
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    engine.nn(nat.DIR_LEFT)
+    engine.set_colors(0, ua / 255.0); engine.set_colors(1, ub / 255.0)
+    want = [engine.color_reduce(nat.DIR_LEFT, s, 255.0 if s == "rgb" else 1.0) for s in ("rgb", "ycc", "yuv")]
+    engine.set_colors_u8(0, ua); engine.set_colors_u8(1, ub)
+    got = [engine.color_reduce(nat.DIR_LEFT, s, 255.0 if s == "rgb" else 1.0) for s in ("rgb", "ycc", "yuv")]
+    for (s0, m0), (s1, m1) in zip(want, got):
+        assert same_bits(s0, s1) and same_bits(m0, m1)
+    assert np.array_equal(engine.color_rows(nat.DIR_LEFT, "rgb", nat.COLOR_OWN), ua / 255.0)
+    with pytest.raises(ValueError):
+        engine.set_colors_u8(0, ua[:10])

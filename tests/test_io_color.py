@@ -235,3 +235,16 @@ def test_xyzrgb_and_pts_readers(tmp_path):
         read_point_cloud(str(tmp_path / "short.pts"))
     with pytest.raises(ValueError):
         read_point_cloud(str(tmp_path / "cloud.obj"))
+
+
+def test_readers_keep_the_uchar_colours_for_the_gpu(tmp_path):
+    rng = np.random.default_rng(8)
+    pts, rgb = rng.random((40, 3)), rng.integers(0, 256, (40, 3))
+    p = str(tmp_path / "c.ply")
+    write_point_cloud(p, PointCloud(pts, None, rgb / 255.0))
+    cloud = read_point_cloud(p)
+    assert cloud.colors_u8 is not None and cloud.colors_u8.dtype == np.uint8
+    assert np.array_equal(cloud.colors_u8, rgb) and np.array_equal(np.asarray(cloud.colors), rgb / 255.0)
+    cloud.colors = np.asarray(cloud.colors) * 0.5          # new colours: the companion no longer applies
+    assert cloud.colors_u8 is None
+    assert PointCloud(pts, None, rgb / 255.0).colors_u8 is None
