@@ -87,34 +87,44 @@ namespace pccm {
 
 constexpr int kMaxDirs = 1024;
 
+// Lanes own directions (16 each: 1024 per wave), waves own slices of the cloud: a point's coordinates are the same for
+// every lane (one broadcast load), so the running maxima stay in registers and nothing is reduced across lanes; a wave
+// meets the other waves only at the end, with one conditional atomicMax per direction.
+constexpr int kDirsPerLane = kMaxDirs / 64;
+
 __global__ __launch_bounds__(256) void k_extreme_rows(const double *__restrict__ x64, int64_t n, const float *__restrict__ dirs, int ndirs,
                                                       unsigned long long *__restrict__ best /*[ndirs]: (ordered dot << 32) | row*/)
 {
-    __shared__ float s_dir[kMaxDirs * 3];
-    __shared__ unsigned long long s_best[kMaxDirs];
-    for (int k = threadIdx.x; k < ndirs * 3; k += 256) s_dir[k] = dirs[k];
-    for (int k = threadIdx.x; k < ndirs; k += 256) s_best[k] = 0ull;
-    __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 255) / 256 * 256; i += (int64_t)gridDim.x * 256) {
-        const bool live = i < n;
-        const float x = live ? (float)x64[3 * i] : 0.f, y = live ? (float)x64[3 * i + 1] : 0.f, z = live ? (float)x64[3 * i + 2] : 0.f;
-        for (int k = 0; k < ndirs; ++k) {
-            const float d = s_dir[3 * k] * x + s_dir[3 * k + 1] * y + s_dir[3 * k + 2] * z;
-            uint32_t b = __float_as_uint(d);
-            b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                      // order-preserving key
-            unsigned long long key = live ? (((unsigned long long)b << 32) | (unsigned long long)(uint32_t)i) : 0ull;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (int64_t)gridDim.x * 4;
+    float dx[kDirsPerLane], dy[kDirsPerLane], dz[kDirsPerLane];
+    unsigned long long mine[kDirsPerLane];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(key, off);
-                key = o > key ? o : key;
-            }
-            if (lane == 0 && key > s_best[k]) atomicMax(&s_best[k], key);
+    for (int j = 0; j < kDirsPerLane; ++j) {
+        const int k = lane + 64 * j;
+        dx[j] = k < ndirs ? dirs[3 * k] : 0.f;
+        dy[j] = k < ndirs ? dirs[3 * k + 1] : 0.f;
+        dz[j] = k < ndirs ? dirs[3 * k + 2] : 0.f;
+        mine[j] = 0ull;
+    }
+    const int64_t per = (n + nwaves - 1) / nwaves;
+    const int64_t i0 = wave * per, i1 = (i0 + per < n) ? i0 + per : n;
+    for (int64_t i = i0; i < i1; ++i) {                                            // wave-uniform: broadcast loads
+        const float x = (float)x64[3 * i], y = (float)x64[3 * i + 1], z = (float)x64[3 * i + 2];
+#pragma unroll
+        for (int j = 0; j < kDirsPerLane; ++j) {
+            const float d = dx[j] * x + dy[j] * y + dz[j] * z;
+            uint32_t b = __float_as_uint(d);
+            b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                          // order-preserving key
+            const unsigned long long key = ((unsigned long long)b << 32) | (unsigned long long)(uint32_t)i;
+            mine[j] = key > mine[j] ? key : mine[j];
         }
     }
-    __syncthreads();
-    for (int k = threadIdx.x; k < ndirs; k += 256)
-        if (s_best[k]) atomicMax(&best[k], s_best[k]);
+#pragma unroll
+    for (int j = 0; j < kDirsPerLane; ++j) {
+        const int k = lane + 64 * j;
+        if (k < ndirs && mine[j] > __hip_atomic_load(&best[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&best[k], mine[j]);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_outside_planes(const double *__restrict__ x64, int64_t n, const double *__restrict__ planes,
