@@ -194,8 +194,8 @@ __global__ __launch_bounds__(kSumThreads) void k_color_colsum(const double *__re
             double t = s;
             const int64_t left = n - base;
             const int groups = (int)((left < kSumChunk ? left : kSumChunk) + 63) / 64;
+            Units qg = units_of(t);                     // ilogb / ldexp are costly: only redone after a plain-sum group
             for (int g = 0; g < groups; ++g) {
-                const Units qg = units_of(t);
                 double k;
                 const bool okg = unit_round(s_x[g * 64 + lane], qg, k) && qg.usable;
                 double tot = k;
@@ -203,8 +203,10 @@ __global__ __launch_bounds__(kSumThreads) void k_color_colsum(const double *__re
                 for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
                 if (__all(okg) && tot <= qg.room) {
                     t = t + tot * qg.u;
+                    qg.room -= tot;                     // exact (integers below 2^53): still t's distance to 2^(e+1) in units
                 } else {
                     for (int e = 0; e < 64; ++e) t = t + s_x[g * 64 + e];     // the reference's own order
+                    qg = units_of(t);
                 }
             }
             if (lane == 0) s_sum = t;
