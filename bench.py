@@ -62,6 +62,31 @@ def cpu_baseline(a, b, na, nb):
                       f"+ D1/D2 reductions, {dt:.2f} s"}, rep, (hl, hr)
 
 
+def cpu_reference_pattern(a, b, na, nb, sample=20000):
+    """The reference's own calling pattern on the CPU, on a prefix of the workload: one Python-level nearest-neighbour
+    call per point out of np.apply_along_axis (cloud_pair.py:16-32) and one np.dot per point for D2 (metric.py:146-153),
+    single thread -- against the oracle's kd-tree instead of Open3D's (absent here).  Scaled linearly to a rate."""
+    from oracle import oracle as orc
+    m = min(sample, a.shape[0], b.shape[0])
+    a64, b64, nb64 = a.astype(np.float64), b.astype(np.float64), nb.astype(np.float64)
+    tree = orc.KDTree(b64)                                     # the full searched cloud, as in the reference
+    t0 = time.perf_counter()
+    found = np.apply_along_axis(lambda p: tree.search_1nn(p), 1, a64[:m])          # (idx, d2) per point
+    idx = found[:, 0].astype(np.int64)
+    err = a64[:m] - b64[idx]
+    proj = np.zeros(m)
+    for i in range(m):                                                         # metric.py:148-152
+        proj[i] = np.dot(err[i], nb64[i])
+    mse1, mse2 = np.sum(found[:, 1]) / m, np.sum(np.square(proj)) / m
+    dt = time.perf_counter() - t0
+    tree.close()
+    # one direction of m points measured; a step is both directions over all N points
+    return {"value": m / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "reference calling pattern on the oracle's kd-tree",
+            "sample": f"{m} of {a.shape[0]} points of one direction (search in the full other cloud, kd-tree build excluded), "
+                      f"{dt:.2f} s; rate assumed linear in the number of query points", "d1_mse_of_sample": float(mse1),
+            "d2_mse_of_sample": float(mse2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +262,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, rep, hd = cpu_baseline(a, b, na, nb)
         line["cpu_baseline"] = base
+        line["cpu_reference_pattern"] = cpu_reference_pattern(a, b, na, nb)
         # same-run parity gate: every row of the step equals the oracle bit for bit
         bad = [k for k, v in rep.items() if k in result and not (result[k] == v)]
         bad += [k for k, v in zip(hd_rows, hd) if not (result[k] == v)]

@@ -123,6 +123,32 @@ def nn(iter_pts, search_pts, *, skip_same_index: bool = False, method: str = "au
     return idx, d2
 
 
+class KDTree:
+    """A kd-tree kept across calls, queried ONE point at a time: the reference's calling pattern (one
+    ``search_knn_vector_3d`` call per point out of ``np.apply_along_axis``, cloud_pair.py:16-32).  bench.py times it."""
+
+    def __init__(self, points):
+        self._lib = _load()
+        self._pts = _f64(points)
+        self._tree = self._lib.orc_kdtree_build(_dp(self._pts), self._pts.shape[0])
+        self._idx = np.empty(1, dtype=np.int64)
+        self._d2 = np.empty(1, dtype=np.float64)
+
+    def search_1nn(self, point) -> Tuple[int, float]:
+        q = np.ascontiguousarray(point, dtype=np.float64).reshape(1, 3)
+        rc = self._lib.orc_kdtree_query(self._tree, _dp(q), 1, 0, _ip(self._idx), _dp(self._d2), 1)
+        if rc != 0:
+            raise RuntimeError(f"oracle kd-tree query failed rc={rc}")
+        return int(self._idx[0]), float(self._d2[0])
+
+    def close(self):
+        if self._tree:
+            self._lib.orc_kdtree_free(self._tree)
+            self._tree = None
+
+    __del__ = close
+
+
 def point_to_plane(iter_pts, search_pts, nn_idx, other_normals, *, normal_index: str = "row") -> np.ndarray:
     """ErrorVector(point_to_plane=True).value, metric.py:146-153.
 
