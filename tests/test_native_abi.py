@@ -53,3 +53,15 @@ def test_finish_sum_is_numpy_sum(n):
     got = nat.finish_sum(xvec, n)
     want = np.sum(col, axis=0)
     assert got == want, (got, want)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/pccm.h is what a cgo / JNI / N-API binding would include: it must compile as C99 on its own."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "pccm.h"\nint main(void) { return pccm_version() > 0 ? 0 : 1; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
