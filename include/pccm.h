@@ -17,7 +17,8 @@
  *   - direction PCCM_DIR_LEFT iterates A and searches B (cloud_pair.py:67-72), PCCM_DIR_RIGHT
  *     iterates B and searches A (cloud_pair.py:73-78), PCCM_DIR_SELF iterates A and searches A
  *     for the nearest point with a different row index (cloud_pair.py:108-109).
- *   - a context belongs to one host thread at a time; different contexts may run concurrently.
+ *   - a context serves one caller at a time: every entry point holds the context's (recursive) mutex for its whole
+ *     duration, so threads that share one are serialised, not corrupted; different contexts run concurrently.
  *   - one context drives one GPU.  Multi-GPU = one process (and context) per GPU, each with
  *     pccm_set_shard(rank, world); the only cross-rank data are the small vectors documented at
  *     pccm_reduce(), which the host exchanges with an RCCL all-reduce (DESIGN.md section e).

@@ -174,10 +174,11 @@ static int upload(pccm_ctx *ctx, const void *src, size_t bytes, int on_device, c
 
 using namespace pccm;
 
-#define CHECK_CTX(ctx)                                          \
-    do {                                                        \
-        if (!(ctx)) return fail(PCCM_E_ARG, "null context");    \
-        hipError_t _e = hipSetDevice((ctx)->device);            \
+#define CHECK_CTX(ctx)                                                                            \
+    if (!(ctx)) return fail(PCCM_E_ARG, "null context");                                          \
+    std::lock_guard<std::recursive_mutex> ctx_guard_((ctx)->mu);                                  \
+    do {                                                                                          \
+        hipError_t _e = hipSetDevice((ctx)->device);                                              \
         if (_e != hipSuccess) return fail(PCCM_E_HIP, "hipSetDevice: %s", hipGetErrorString(_e)); \
     } while (0)
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -138,6 +139,9 @@ struct GraphRec {
 }  // namespace pccm
 
 struct pccm_ctx {
+    // one context = one caller at a time: every entry point holds this for its whole duration (recursive: entry points
+    // call each other), so threads that share a context by mistake are serialised instead of corrupting it
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

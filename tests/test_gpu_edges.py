@@ -263,3 +263,32 @@ def test_pooled_context_starts_clean():
     with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1]) as again:
         got = MetricCalculator(again).calculate(opts).as_dict()
     assert list(got) == list(want) and all(np.float64(got[k]) == np.float64(want[k]) for k in want)
+
+
+def test_threads_sharing_a_context_are_serialised(engine):
+    """One context is meant for one caller at a time; threads that share it anyway (ctypes releases the GIL inside every
+    call) queue on the context's mutex instead of corrupting it."""
+    import threading
+    rng = np.random.default_rng(41)
+    a, b = rng.random((20000, 3)), rng.random((20000, 3))
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    oi, od = orc.nn(a, b, method="kdtree")
+    errors = []
+
+    def worker():
+        try:
+            for _ in range(20):
+                engine.drop_caches()
+                engine.nn(nat.DIR_LEFT, "grid")
+                idx, d2 = engine.fetch_nn(nat.DIR_LEFT)
+                if not (np.array_equal(idx, oi) and np.array_equal(d2, od)):
+                    errors.append("mismatch")
+        except Exception as ex:            # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
