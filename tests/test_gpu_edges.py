@@ -292,3 +292,32 @@ def test_threads_sharing_a_context_are_serialised(engine):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_two_pairs_in_two_threads_run_concurrently():
+    """Different contexts are independent: two host threads, one CloudPair each, reports in parallel."""
+    import threading
+    opts = transform_options(CalculateOptions(None, True, True))
+    results, errors = {}, []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            a, b = rng.random((15000, 3)), rng.random((15000, 3))
+            na, nb = rng.standard_normal((15000, 3)), rng.standard_normal((15000, 3))
+            want = orc.OraclePair(a, b, na, nb, method="kdtree").report(hausdorff=True, point_to_plane_=True, peak=1.0)
+            for _ in range(5):
+                with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1]) as pair:
+                    got = MetricCalculator(pair).calculate(opts).as_dict()
+                if any(np.float64(got[k]) != np.float64(want[k]) for k in want):
+                    errors.append(f"mismatch in thread {seed}")
+            results[seed] = True
+        except Exception as ex:            # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (51, 52)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(results) == 2, errors[:3]
