@@ -297,11 +297,11 @@ def test_threads_sharing_a_context_are_serialised(engine):
 def test_two_pairs_in_two_threads_run_concurrently():
     """Different contexts are independent: two host threads, one CloudPair each, reports in parallel."""
     import threading
-    opts = transform_options(CalculateOptions(None, True, True))
     results, errors = {}, []
 
     def worker(seed):
         try:
+            opts = transform_options(CalculateOptions(None, True, True))      # metric objects carry values: one set per thread
             rng = np.random.default_rng(seed)
             a, b = rng.random((15000, 3)), rng.random((15000, 3))
             na, nb = rng.standard_normal((15000, 3)), rng.standard_normal((15000, 3))
