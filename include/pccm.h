@@ -128,6 +128,15 @@ int pccm_nn(pccm_ctx *ctx, int dir, int engine);
  * Same results as two pccm_nn() calls; the grid engine fuses both directions into the same launches. */
 int pccm_nn_pair(pccm_ctx *ctx, int engine);
 
+/* Fuse the point-to-plane projection of direction `dir` (0 or 1) into the search: every settled query then also
+ * leaves err . normal_other[row] (normal_mode PCCM_NORMAL_ROW: row i of the searched cloud's normals, what
+ * metric.py:146-153 of the reference computes; PCCM_NORMAL_NEIGHBOUR: row nn(i)), so that the D2 reductions
+ * (metric.py:179, 226-228, 366) need no second pass over the points.  normal_mode -1 switches it off.  A request
+ * that cannot be honoured at search time (no normals set, row-indexed normals shorter than the iterating cloud)
+ * is ignored; the reductions then take the separate pass and report the reference's IndexError (PCCM_E_RANGE).
+ * Purely an optimisation: results are bit-identical either way.  Takes effect at the next pccm_nn / pccm_nn_pair. */
+int pccm_nn_fuse(pccm_ctx *ctx, int dir, int normal_mode);
+
 /* Copy the shard's results to the host (either pointer may be NULL).  idx[i] is the row in
  * the searched cloud, d2[i] the squared distance: the (idxs, sqrdists) of cloud_pair.py:32-33
  * and the value behind get_left/right_neighbour_distances(), cloud_pair.py:102-106. */

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import sys
+import threading
 from typing import Optional, Tuple
 
 import numpy as np
@@ -28,7 +29,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
-    "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fetch",
+    "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
     "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
@@ -45,6 +46,15 @@ _lib = None
 
 class NativeLibraryMissing(ImportError):
     pass
+
+
+class PccmStateError(RuntimeError):
+    """PCCM_E_STATE: a call came in the wrong order or hit a stale object (a hipGraph captured before buffers
+    changed, a reduction before its search).  The context is intact; callers may recover (CloudPair re-captures)."""
+
+
+class PccmDeviceError(RuntimeError):
+    """PCCM_E_HIP / PCCM_E_NODEV: the HIP runtime reported a failure.  Never retried, never swallowed."""
 
 
 def load() -> ctypes.CDLL:
@@ -82,6 +92,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_shard_range.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.pccm_nn.argtypes = [vp, i32, i32]
     lib.pccm_nn_pair.argtypes = [vp, i32]
+    lib.pccm_nn_fuse.argtypes = [vp, i32, i32]
     lib.pccm_nn_fetch.argtypes = [vp, i32, vp, vp]
     lib.pccm_error_vectors.argtypes = [vp, i32, vp]
     lib.pccm_point_metric.argtypes = [vp, i32, i32, i32, vp]
@@ -131,6 +142,10 @@ def _check(rc: int) -> None:
         raise IndexError(msg)
     if rc == E_OOM:
         raise MemoryError(msg)
+    if rc == E_STATE:
+        raise PccmStateError(f"libpccm error {rc}: {msg}")
+    if rc in (E_HIP, E_NODEV):
+        raise PccmDeviceError(f"libpccm error {rc}: {msg}")
     raise RuntimeError(f"libpccm error {rc}: {msg}")
 
 
@@ -179,34 +194,45 @@ def lzf_decompress(data: bytes, size: int) -> bytes:
 # hands it back when it dies; a caller that evaluates one pair after the other pays the work, not the lifecycle.
 _POOL: dict = {}
 _POOL_MAX = 2
+_POOL_LOCK = threading.Lock()      # evaluate_pairs drives the pool from several host threads; __del__ may run on any
 
 
 def acquire_engine(device: int = 0) -> "Engine":
-    pool = _POOL.get(int(device))
-    while pool:
-        eng = pool.pop()
+    while True:
+        with _POOL_LOCK:
+            pool = _POOL.get(int(device))
+            eng = pool.pop() if pool else None
+        if eng is None:
+            return Engine(device)
         try:
             eng.reset()
             return eng
-        except Exception:                      # noqa: BLE001 -- a context that cannot be reset is not worth keeping
+        except PccmStateError:                 # a context that cannot be reset is not worth keeping
             eng.close()
-    return Engine(device)
+        # anything else (a HIP failure in particular) propagates: it is not ours to hide
 
 
 def release_engine(eng: "Engine") -> None:
     if not getattr(eng, "_ctx", None) or not eng._ctx.value:
         return                                 # closed by hand
-    pool = _POOL.setdefault(eng.device, [])
-    if len(pool) < _POOL_MAX and eng not in pool:
-        pool.append(eng)
-    elif eng not in pool:
+    with _POOL_LOCK:
+        pool = _POOL.setdefault(eng.device, [])
+        if eng in pool:
+            return
+        keep = len(pool) < _POOL_MAX
+        if keep:
+            pool.append(eng)
+    if not keep:
         eng.close()
 
 
 def drain_pool() -> None:
-    for pool in _POOL.values():
-        while pool:
-            pool.pop().close()
+    while True:
+        with _POOL_LOCK:
+            eng = next((pool.pop() for pool in _POOL.values() if pool), None)
+        if eng is None:
+            return
+        eng.close()
 
 
 import atexit  # noqa: E402
@@ -372,6 +398,10 @@ class Engine:
     def nn_pair(self, engine: str = "auto") -> None:
         """Both directional sweeps of CloudPair.__init__ (cloud_pair.py:67-78) in one call."""
         _check(self._lib.pccm_nn_pair(self._ctx, ENGINES[engine]))
+
+    def nn_fuse(self, direction: int, normal_mode: Optional[str]) -> None:
+        """Fuse the D2 projection of ``direction`` into the next searches (pccm_nn_fuse); ``None`` switches it off."""
+        _check(self._lib.pccm_nn_fuse(self._ctx, int(direction), -1 if normal_mode is None else NORMAL_MODES[normal_mode]))
 
     def fetch_nn(self, direction: int, want_idx: bool = True, want_d2: bool = True):
         b, e = self.shard_range(direction)

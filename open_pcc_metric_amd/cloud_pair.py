@@ -272,6 +272,7 @@ class CloudPair:
                 _engine.set_normals(k, cloud.normals)
         if self._coll.sharded:
             _engine.set_shard(self._coll.rank, self._coll.world)
+        self._update_fusion()
         self.recompute()
 
     def close(self) -> None:
@@ -292,6 +293,16 @@ class CloudPair:
     def __exit__(self, *exc):
         self.close()
 
+    def _update_fusion(self) -> None:
+        """Let the searches leave the D2 projection next to the distance (pccm_nn_fuse) for every direction whose
+        *other* cloud has normals: a report then needs no second pass over the points (metric.py:146-153 fused into
+        cloud_pair.py:67-78).  Purely an optimisation; the library ignores what it cannot honour."""
+        eng = self._engine
+        if not hasattr(eng, "nn_fuse"):
+            return
+        for direction, other in ((nat.DIR_LEFT, 1), (nat.DIR_RIGHT, 0)):
+            eng.nn_fuse(direction, self.normal_index if self._normals_ready(other) else None)
+
     def recompute(self) -> None:
         """Run both directional sweeps again on the clouds already resident in HBM
         (cloud_pair.py:67-78 does this once, eagerly, in the constructor) and drop cached results."""
@@ -306,8 +317,9 @@ class CloudPair:
                     eng.graph_launch(self._graph_id)          # sweeps + the last report's reductions, one launch
                     self._self_done = wants_self
                     return
-                except RuntimeError:
+                except nat.PccmStateError:
                     self._graph_id = None                     # stale (buffers changed): run eagerly, capture again later
+                # anything else -- a HIP failure during the replay in particular -- is not retried and not hidden
             else:
                 try:
                     eng.graph_begin()
@@ -317,10 +329,14 @@ class CloudPair:
                     self._graph_id = eng.graph_end()
                     self._self_done = wants_self
                     return
-                except (RuntimeError, ValueError, IndexError):
+                except (nat.PccmStateError, ValueError, IndexError):
                     eng.graph_abort()                         # leave capture mode; results were invalidated
                     self._graph_id = None
                     self._use_graph = False                   # capture not possible here: stay eager
+                except BaseException:
+                    eng.graph_abort()                         # leave capture mode, then let the failure surface
+                    self._graph_id = None
+                    raise
         self._enqueue_sweeps()
         self._self_done = False
 
@@ -393,6 +409,7 @@ class CloudPair:
         self._engine.estimate_normals(which, self._normals_knn)      # stays in HBM; inputs are not touched
         self._estimated[which] = True
         self._graph_id = None                                        # device buffers changed
+        self._update_fusion()                                        # the next sweeps carry the projection along
 
     # -- reference surface, cloud_pair.py:82-124 -------------------------------------------------
     @property
@@ -512,8 +529,9 @@ class CloudPair:
                     continue          # surfaces when the column is evaluated
                 n_other = self._engine.n_iter(nat.DIR_RIGHT if other else nat.DIR_LEFT) if self._estimated[other] \
                     else len(self.clouds[other].normals)
-                if self.normal_index == "row" and eng.shard_range(direction)[1] > n_other:
-                    continue      # row-indexed normals out of range: surfaces where the reference raises
+                if self.normal_index == "row" and eng.n_iter(direction) > n_other:
+                    continue      # row-indexed normals out of range (the WHOLE cloud decides, so that every rank of a
+                    #               sharded pair agrees): surfaces, on every rank, where the reference raises
                 requests.append((direction, nat.METRIC_D2))
         self._xchg_wanted = list(requests)
         if not can_prefetch:

@@ -130,6 +130,8 @@ static void free_nn(NNResult &r)
     free_buf(r.flagged);
     free_buf(r.flag_thr);
     free_buf(r.tail);
+    free_buf(r.rec);
+    r.rec_valid = r.plain_valid = false;
     if (r.idx) (void)hipFree(r.idx);
     if (r.d2) (void)hipFree(r.d2);
     r.idx = nullptr;
@@ -183,6 +185,7 @@ using namespace pccm;
     } while (0)
 
 static void graph_free(GraphRec &g);
+static int ensure_plain(pccm_ctx *ctx, NNResult &res);
 
 #define NOT_CAPTURING(ctx)                                                                          \
     do {                                                                                           \
@@ -425,10 +428,12 @@ static int color_operands(pccm_ctx *ctx, int dir, int scheme, const int32_t *row
         PCCM_HIP(hipMemcpyAsync(ctx->color_idx.p, rows, (size_t)nrows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         *drows = (const int32_t *)ctx->color_idx.p;
     } else {
-        const NNResult &res = ctx->nn[dir];
+        NNResult &res = ctx->nn[dir];
         if (!res.valid) return fail(PCCM_E_STATE, "run pccm_nn for direction %d first", dir);
         if (res.begin != 0 || res.end != it.n)
             return fail(PCCM_E_STATE, "the search of direction %d was sharded: pass the gathered neighbour rows", dir);
+        int rc = ensure_plain(ctx, res);
+        if (rc) return rc;
         *drows = res.idx;
     }
     *own = &it;
@@ -659,6 +664,13 @@ static int prepare_nn(pccm_ctx *ctx, int dir, int *trivial)
         PCCM_HIP(hipMalloc((void **)&res.d2, (size_t)ns * sizeof(double)));
         res.cap = ns;
     }
+    {
+        int rc2 = ensure(ctx, res.rec, (size_t)(ns > 0 ? ns : 1) * sizeof(double4));   // 32-byte result records (grid engine)
+        if (rc2) return rc2;
+    }
+    res.rec_valid = false;
+    res.plain_valid = ns <= 0;          // an empty shard has nothing to unpack
+    res.fused_mode = -1;
     res.stats[0] = res.stats[1] = res.stats[2] = 0;
     *trivial = 0;
     if (dir == PCCM_DIR_SELF && it->n < 2) {
@@ -668,6 +680,7 @@ static int prepare_nn(pccm_ctx *ctx, int dir, int *trivial)
             PCCM_HIP(hipMemsetAsync(res.d2, 0, (size_t)ns * sizeof(double), ctx->stream));
         }
         PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
+        res.plain_valid = true;
         *trivial = 1;
     }
     return PCCM_OK;
@@ -706,6 +719,7 @@ static int run_nn(pccm_ctx *ctx, int ndirs, const int *dirs, int engine)
         for (int k = 0; k < ntodo; ++k) {
             const Cloud *it, *se;
             if ((rc = dir_clouds(ctx, todo[k], &it, &se))) return rc;
+            ctx->nn[todo[k]].plain_valid = true;                 // the brute-force engine writes the plain columns
             if ((rc = nn_brute(ctx, *it, *se, todo[k] == PCCM_DIR_SELF, ctx->nn[todo[k]]))) return rc;
         }
     }
@@ -736,6 +750,32 @@ static int need_nn(pccm_ctx *ctx, int dir, const Cloud **it, const Cloud **se, N
     return PCCM_OK;
 }
 
+// the plain idx / d2 columns of a result: the grid engine leaves 32-byte records, unpacked here when somebody
+// wants columns (getters, colour kernels, the separate point kernel)
+static int ensure_plain(pccm_ctx *ctx, NNResult &res)
+{
+    if (res.plain_valid) return PCCM_OK;
+    if (!res.rec_valid) return fail(PCCM_E_STATE, "no nearest-neighbour result to read");
+    int rc = launch_unpack(ctx, (const double4 *)res.rec.p, res.end - res.begin, res.idx, res.d2);
+    if (rc) return rc;
+    res.plain_valid = true;
+    return PCCM_OK;
+}
+
+int pccm_nn_fuse(pccm_ctx *ctx, int dir, int normal_mode)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (dir != PCCM_DIR_LEFT && dir != PCCM_DIR_RIGHT) return fail(PCCM_E_ARG, "the projection exists for directions 0 and 1");
+    if (normal_mode != -1 && normal_mode != PCCM_NORMAL_ROW && normal_mode != PCCM_NORMAL_NEIGHBOUR)
+        return fail(PCCM_E_ARG, "bad normal mode %d", normal_mode);
+    if (ctx->fuse_mode[dir] != normal_mode) {
+        ctx->fuse_mode[dir] = normal_mode;
+        ctx->epoch++;                                        // captured searches carry the old choice
+    }
+    return PCCM_OK;
+}
+
 int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
 {
     CHECK_CTX(ctx);
@@ -744,6 +784,7 @@ int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
     NNResult *res;
     int rc = need_nn(ctx, dir, &it, &se, &res);
     if (rc) return rc;
+    if ((rc = ensure_plain(ctx, *res))) return rc;
     const int64_t ns = res->end - res->begin;
     if (ns > 0 && idx) PCCM_HIP(hipMemcpyAsync(idx, res->idx, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (ns > 0 && d2) PCCM_HIP(hipMemcpyAsync(d2, res->d2, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -751,12 +792,14 @@ int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
     return PCCM_OK;
 }
 
-static int check_normals(const Cloud &se, const NNResult &res, int normal_mode)
+static int check_normals(const pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int normal_mode)
 {
     if (normal_mode != PCCM_NORMAL_ROW && normal_mode != PCCM_NORMAL_NEIGHBOUR)
         return fail(PCCM_E_ARG, "bad normal mode %d", normal_mode);
     if (se.n_nrm <= 0) return fail(PCCM_E_STATE, "the searched cloud has no normals (pccm_set_normals)");
-    if (normal_mode == PCCM_NORMAL_ROW && res.end > se.n_nrm)
+    // sharded: the test is on the whole iterating cloud, so that every rank raises (or none does) -- a per-shard test
+    // would let the low ranks walk into the exchange while the last one raises
+    if (normal_mode == PCCM_NORMAL_ROW && (ctx->world > 1 ? it.n : res.end) > se.n_nrm)
         return fail(PCCM_E_RANGE, "index %lld is out of bounds for axis 0 with size %lld (row-indexed normals, reference quirk Q1)",
                     (long long)se.n_nrm, (long long)se.n_nrm);
     if (normal_mode == PCCM_NORMAL_NEIGHBOUR && se.n_nrm != se.n)
@@ -775,6 +818,7 @@ int pccm_error_vectors(pccm_ctx *ctx, int dir, double *out)
     if (rc) return rc;
     const int64_t ns = res->end - res->begin;
     if (ns <= 0) return PCCM_OK;
+    if ((rc = ensure_plain(ctx, *res))) return rc;
     if ((rc = ensure(ctx, ctx->val, (size_t)ns * 3 * sizeof(double)))) return rc;
     if ((rc = launch_point_metric(ctx, *it, *se, *res, PCCM_METRIC_D1, PCCM_NORMAL_ROW, nullptr, (double *)ctx->val.p))) return rc;
     PCCM_HIP(hipMemcpyAsync(out, ctx->val.p, (size_t)ns * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -795,13 +839,14 @@ static int metric_on_device(pccm_ctx *ctx, int dir, int metric, int normal_mode,
     *ns_out = ns;
     *it_out = it;
     *res_out = res;
+    if ((rc = ensure_plain(ctx, *res))) return rc;
     if (metric == PCCM_METRIC_D1) {
         *dev = res->d2;
         return PCCM_OK;
     }
     if (metric != PCCM_METRIC_D2 && metric != PCCM_METRIC_PROJ) return fail(PCCM_E_ARG, "bad metric %d", metric);
     if (dir == PCCM_DIR_SELF) return fail(PCCM_E_ARG, "point-to-plane is not defined for the self search");
-    if ((rc = check_normals(*se, *res, normal_mode))) return rc;
+    if ((rc = check_normals(ctx, *it, *se, *res, normal_mode))) return rc;
     if ((rc = ensure(ctx, vb, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
     if ((rc = launch_point_metric(ctx, *it, *se, *res, metric, normal_mode, (double *)vb.p, nullptr))) return rc;
     *dev = (const double *)vb.p;
@@ -844,19 +889,38 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     int rc = need_nn(ctx, dir, &it, &se, &res);
     if (rc) return rc;
     const int64_t ns = res->end - res->begin;
-    const double *dev = res->d2;
-    if (metric != PCCM_METRIC_D1) {
+    // where the column lives: a field of the grid engine's 32-byte result records (squared distance, or the signed
+    // projection fused into the search by pccm_nn_fuse), or a plain column (brute-force engine; unfused projection)
+    const double *dev = nullptr;
+    int stride = 1, square = 0;
+    if (metric == PCCM_METRIC_D1) {
+        if (res->rec_valid) {
+            dev = (const double *)res->rec.p;
+            stride = 4;
+        } else {
+            if ((rc = ensure_plain(ctx, *res))) return rc;
+            dev = res->d2;
+        }
+    } else {
         if (metric != PCCM_METRIC_D2 && metric != PCCM_METRIC_PROJ) return fail(PCCM_E_ARG, "bad metric %d", metric);
         if (dir == PCCM_DIR_SELF) return fail(PCCM_E_ARG, "point-to-plane is not defined for the self search");
-        if ((rc = check_normals(*se, *res, normal_mode))) return rc;
-        if ((rc = ensure(ctx, s.val, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
-        dev = (const double *)s.val.p;
-        if (ns > 0) {
-            PointJob &P = pj.j[pj.njobs];
-            P.q64 = it->xyz64; P.r64 = se->xyz64; P.nrm = se->nrm64; P.idx = res->idx;
-            P.q_begin = res->begin; P.metric = metric; P.normal_mode = normal_mode; P.val = (double *)s.val.p;
-            pj.off[pj.njobs + 1] = pj.off[pj.njobs] + ns;
-            pj.njobs++;
+        if ((rc = check_normals(ctx, *it, *se, *res, normal_mode))) return rc;
+        if (res->rec_valid && res->fused_mode == normal_mode) {
+            dev = (const double *)res->rec.p + 1;
+            stride = 4;
+            square = metric == PCCM_METRIC_D2 ? 1 : 0;       // metric.py:179: the square of the stored projection
+        } else {
+            if ((rc = ensure_plain(ctx, *res))) return rc;
+            if ((rc = ensure(ctx, s.val, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
+            dev = (const double *)s.val.p;
+            if (ns > 0) {
+                if (pj.njobs >= 4) return fail(PCCM_E_ARG, "at most four unfused point-to-plane columns per call");
+                PointJob &P = pj.j[pj.njobs];
+                P.q64 = it->xyz64; P.r64 = se->xyz64; P.nrm = se->nrm64; P.idx = res->idx;
+                P.q_begin = res->begin; P.metric = metric; P.normal_mode = normal_mode; P.val = (double *)s.val.p;
+                pj.off[pj.njobs + 1] = pj.off[pj.njobs] + ns;
+                pj.njobs++;
+            }
         }
     }
     s.dir = dir; s.metric = metric; s.mode = normal_mode;
@@ -883,7 +947,7 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     if (!s.ev) PCCM_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
     if (s.nunits > 0) {
         UnitJob &U = uj.j[uj.njobs];
-        U.val = dev; U.ns = ns; U.nunits = s.nunits;
+        U.val = dev; U.stride = stride; U.square = square; U.ns = ns; U.nunits = s.nunits;
         U.tail_first = s.t0 - res->begin; U.tail_n = s.tail_n;
         U.nblocks = s.nblocks;
         U.out_units = want_units ? s.host : nullptr;
@@ -934,7 +998,6 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
     for (int k = 0; k < n; ++k) {
         if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
         if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k], want_units)) continue;
-        if (pj.njobs >= 4 && metrics[k] != PCCM_METRIC_D1) return fail(PCCM_E_ARG, "at most four point-to-plane columns per call");
         ReduceSlot *s = slot_free(ctx);
         if (s->pending && !ctx->capturing) PCCM_HIP(hipEventSynchronize(s->ev));
         s->pending = false;
@@ -1157,6 +1220,9 @@ static int graph_replay(pccm_ctx *ctx, GraphRec &g)
         if (op.kind == 1) {
             ctx->nn_gen[op.dir]++;
             ctx->nn[op.dir].valid = true;
+            ctx->nn[op.dir].rec_valid = op.rec_valid;
+            ctx->nn[op.dir].plain_valid = op.plain_valid;
+            ctx->nn[op.dir].fused_mode = op.fused_mode;
         } else if (op.kind == 2) {
             ReduceSlot &s = ctx->slots[op.slot];
             if (s.pending && s.gen == ctx->nn_gen[s.dir]) PCCM_HIP(hipEventSynchronize(s.ev));   // still in use by someone else
@@ -1214,6 +1280,12 @@ int pccm_graph_end(pccm_ctx *ctx, int *graph_id)
         return fail(PCCM_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
     }
     g.ops = ctx->cap_ops;
+    for (auto &op : g.ops)
+        if (op.kind == 1) {                                // the state the captured sequence leaves behind
+            op.rec_valid = ctx->nn[op.dir].rec_valid;
+            op.plain_valid = ctx->nn[op.dir].plain_valid;
+            op.fused_mode = ctx->nn[op.dir].fused_mode;
+        }
     g.epoch = ctx->epoch;
     g.valid = true;
     // the captured calls changed the host bookkeeping but nothing ran yet: run the graph once now

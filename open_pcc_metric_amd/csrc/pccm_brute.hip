@@ -317,6 +317,33 @@ __device__ __forceinline__ void block_lexmin(double &bd, int &bj, double *s_d, i
     }
 }
 
+// a rescanned query's answer: plain columns (brute-force engine) or a 32-byte result record with the D2
+// projection fused (grid engine; same expression as emit_result in pccm_grid.h / K3 in pccm_point.hip)
+__device__ __forceinline__ void rescan_emit(const RescanJob &J, int64_t i, int bj, double bd)
+{
+    if (!J.rec_out) {
+        J.idx_out[i] = bj;
+        J.d2_out[i] = bd;
+        return;
+    }
+    double p = 0.0;
+    if (J.nrm && bj >= 0 && bj != 0x7fffffff) {
+        const int64_t gi = J.q_begin + i, k = (J.normal_mode == PCCM_NORMAL_ROW) ? gi : (int64_t)bj;
+        const double ex = __dsub_rn(J.q64[3 * gi], J.r64[3 * (int64_t)bj]);
+        const double ey = __dsub_rn(J.q64[3 * gi + 1], J.r64[3 * (int64_t)bj + 1]);
+        const double ez = __dsub_rn(J.q64[3 * gi + 2], J.r64[3 * (int64_t)bj + 2]);
+        p = __dmul_rn(ex, J.nrm[3 * k]);
+        p = __fma_rn(ey, J.nrm[3 * k + 1], p);
+        p = __fma_rn(ez, J.nrm[3 * k + 2], p);
+    }
+    double4 r;
+    r.x = bd;
+    r.y = p;
+    r.z = __longlong_as_double((long long)(uint32_t)bj);
+    r.w = 0.0;
+    J.rec_out[i] = r;
+}
+
 template <bool SELF>
 __global__ __launch_bounds__(256) void k2b_fallback(RescanJobs jobs)
 {
@@ -335,10 +362,7 @@ __global__ __launch_bounds__(256) void k2b_fallback(RescanJobs jobs)
             int bj;
             rescan_slice<SELF>(J, i, J.flag_thr[f], 0, J.nr, tid, bd, bj);
             block_lexmin(bd, bj, s_d, s_j);
-            if (tid == 0) {
-                J.idx_out[i] = bj;
-                J.d2_out[i] = bd;
-            }
+            if (tid == 0) rescan_emit(J, i, bj, bd);
         }
         return;
     }
@@ -369,11 +393,7 @@ __global__ __launch_bounds__(256) void k2b_fallback(RescanJobs jobs)
             if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
         }
         block_lexmin(bd, bj, s_d, s_j);
-        if (tid == 0) {
-            const int64_t i = J.flagged[f];
-            J.idx_out[i] = bj;
-            J.d2_out[i] = bd;
-        }
+        if (tid == 0) rescan_emit(J, J.flagged[f], bj, bd);
     }
     if (tid == 0) *J.ticket = 0u;                    // ready for the next launch
 }
@@ -424,6 +444,10 @@ int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Clo
         J.nflag = res.nflag_dev;
         J.idx_out = res.idx;
         J.d2_out = res.d2;
+        // the grid engine's results are 32-byte records (nn_grid set rec_valid for this run); the brute engine writes columns
+        J.rec_out = res.rec_valid ? (double4 *)res.rec.p : nullptr;
+        J.nrm = (res.rec_valid && res.fused_mode >= 0) ? se.nrm64 : nullptr;
+        J.normal_mode = res.fused_mode >= 0 ? res.fused_mode : PCCM_NORMAL_ROW;
         J.part_d = (double *)ctx->rescan_part.p + (size_t)k * kSplitMax * cap;
         J.part_j = (int32_t *)((double *)ctx->rescan_part.p + (size_t)2 * kSplitMax * cap) + (size_t)k * kSplitMax * cap;
         J.ticket = (uint32_t *)ctx->counters.p + 8 + k + (self ? 2 : 0);

@@ -247,11 +247,12 @@ int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, con
 int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *out3)
 {
     ProfScope ps(ctx, PCCM_K_REDUCE);
-    static bool configured = false;                   // 64 KB of dynamic LDS needs the opt-in once per process
-    if (!configured) {
+    // 64 KB of dynamic LDS needs the opt-in -- a per-DEVICE attribute: kept with the context (which is bound to one
+    // device and serialised by its mutex), not in a process-wide flag
+    if (!ctx->colsum_configured) {
         PCCM_HIP(hipFuncSetAttribute((const void *)k_color_colsum, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kSumChunk * (int)sizeof(double)));
-        configured = true;
+        ctx->colsum_configured = true;
     }
     hipLaunchKernelGGL(k_color_colsum, dim3(3), dim3(kSumThreads), kSumChunk * sizeof(double), ctx->stream, cols, n, out3);
     PCCM_HIP(hipGetLastError());

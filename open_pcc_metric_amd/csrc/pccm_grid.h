@@ -1,0 +1,204 @@
+// Shared device/host declarations of the uniform-grid engine (pccm_grid.hip, pccm_gridbuild.hip, pccm_brick.hip).
+//
+// The grid stands under the two KDTreeFlann builds of open_pcc_metric/cloud_pair.py:65 and the per-point
+// search_knn_vector_3d calls of cloud_pair.py:16-32 (see pccm_grid.hip for the search itself).
+#pragma once
+#include "pccm_internal.h"
+
+namespace pccm {
+
+struct GridGeom {
+    int dim[3];
+    double org[3], h[3], inv_h[3], slack[3];
+};
+
+__device__ __forceinline__ int cell_coord(double v, double org, double inv_h, int dim)
+{
+    double t = floor(__dmul_rn(__dsub_rn(v, org), inv_h));
+    t = t < 0.0 ? 0.0 : t;
+    const double top = (double)(dim - 1);
+    t = t > top ? top : t;
+    return (int)t;
+}
+
+__device__ __forceinline__ uint32_t cell_linear(const GridGeom &g, double x, double y, double z)
+{
+    const int cx = cell_coord(x, g.org[0], g.inv_h[0], g.dim[0]);
+    const int cy = cell_coord(y, g.org[1], g.inv_h[1], g.dim[1]);
+    const int cz = cell_coord(z, g.org[2], g.inv_h[2], g.dim[2]);
+    return ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
+}
+
+__device__ __forceinline__ double gdist64(double qx, double qy, double qz, double rx, double ry, double rz)
+{
+    double dx = __dsub_rn(qx, rx), dy = __dsub_rn(qy, ry), dz = __dsub_rn(qz, rz);
+    double d = __dmul_rn(dx, dx);
+    d = __dadd_rn(d, __dmul_rn(dy, dy));
+    d = __dadd_rn(d, __dmul_rn(dz, dz));
+    return d;
+}
+
+// ---- cell-sorted records -------------------------------------------------------------------------------
+// Two layouts.  GridRec (32 B, pccm_internal.h) carries the fp64 position; Rec32 (16 B) carries the fp32
+// position and is used when BOTH clouds are fp32-exact (every PLY / voxelised input; the benchmark's clouds):
+// (double)(float)x == x then, so every fp64 decision made from a Rec32 is the one made from the originals,
+// at half the bytes per candidate.
+struct Rec32 {
+    float x, y, z;
+    int32_t row;
+};
+
+struct P3 {            // a record as the kernels compute with it
+    double x, y, z;
+    int row;
+};
+
+__device__ __forceinline__ P3 load_rec(const GridRec *__restrict__ recs, uint32_t p)
+{
+    const double4 a = *reinterpret_cast<const double4 *>(&recs[p]);
+    P3 r;
+    r.x = a.x; r.y = a.y; r.z = a.z;
+    r.row = (int)(__double_as_longlong(a.w) & 0xffffffffll);
+    return r;
+}
+
+__device__ __forceinline__ P3 load_rec(const Rec32 *__restrict__ recs, uint32_t p)
+{
+    const float4 a = *reinterpret_cast<const float4 *>(&recs[p]);
+    P3 r;
+    r.x = (double)a.x; r.y = (double)a.y; r.z = (double)a.z;
+    r.row = __float_as_int(a.w);
+    return r;
+}
+
+__device__ __forceinline__ void store_rec(GridRec *__restrict__ recs, uint32_t p, const P3 &v)
+{
+    double4 r;
+    r.x = v.x; r.y = v.y; r.z = v.z;
+    r.w = __longlong_as_double((long long)(uint32_t)v.row);
+    *reinterpret_cast<double4 *>(&recs[p]) = r;
+}
+
+__device__ __forceinline__ void store_rec(Rec32 *__restrict__ recs, uint32_t p, const P3 &v)
+{
+    float4 r;
+    r.x = (float)v.x; r.y = (float)v.y; r.z = (float)v.z;      // exact: Rec32 is only used for fp32-exact clouds
+    r.w = __int_as_float(v.row);
+    *reinterpret_cast<float4 *>(&recs[p]) = r;
+}
+
+// ---- build (pccm_gridbuild.hip) --------------------------------------------------------------------------
+struct BuildJob {
+    const double *x64;   // [.][3]
+    const float *x32;    // quad layout (Cloud::xyz32); read instead of x64 when the records are Rec32
+    int64_t row0, n;     // rows [row0, row0 + n)
+    uint32_t *cs;        // this job's cell starts, [ncells + 1]
+};
+
+struct BuildJobs {
+    BuildJob j[2];
+    int njobs;
+    int64_t total;
+};
+
+// Counting sort of the jobs' rows by cell into `recs` (positions run across the jobs); on return every job's
+// cs[c] holds the position of the first record of cell c and cs[ncells] the end of the job's records.
+int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_t ncells, void *recs, bool rec32);
+
+// scratch sizes (so that callers can allocate before a graph capture)
+int64_t scan_tiles(int64_t m);
+
+// ---- result of one query (all grid kernels and the exact rescan write through this) ---------------------------
+// A settled query leaves ONE 32-byte record in row order: squared distance, signed point-to-plane projection
+// (0 when no normals were attached: pccm_nn_fuse) and the matched row.  One full 32-byte sector per query
+// instead of partial-sector stores into three arrays; the reductions read the records directly.
+struct NNOut {
+    double4 *rec;          // [rows of the shard], indexed row - row_base
+    const double *nrm;     // normals of the searched cloud, [.][3], or null: projection not fused
+    int64_t row_base;
+    int normal_mode;       // PCCM_NORMAL_ROW / PCCM_NORMAL_NEIGHBOUR
+};
+
+__device__ __forceinline__ void emit_result(const NNOut &o, int qrow, double qx, double qy, double qz, int wrow, double d2,
+                                            double rx, double ry, double rz)
+{
+    double p = 0.0;
+    if (o.nrm && wrow >= 0) {
+        // metric.py:146-153: err . normal_other[row]; FMA chain as np.dot evaluates it (see pccm_point.hip, K3)
+        const int64_t k = (o.normal_mode == PCCM_NORMAL_ROW) ? (int64_t)qrow : (int64_t)wrow;
+        const double ex = __dsub_rn(qx, rx), ey = __dsub_rn(qy, ry), ez = __dsub_rn(qz, rz);
+        p = __dmul_rn(ex, o.nrm[3 * k]);
+        p = __fma_rn(ey, o.nrm[3 * k + 1], p);
+        p = __fma_rn(ez, o.nrm[3 * k + 2], p);
+    }
+    double4 r;
+    r.x = d2;
+    r.y = p;
+    r.z = __longlong_as_double((long long)(uint32_t)wrow);
+    r.w = 0.0;
+    o.rec[qrow - o.row_base] = r;
+}
+
+
+// lookup form: the winner's coordinates come from the searched cloud's fp64 rows (rare paths: tails, rescans)
+__device__ __forceinline__ void emit_result_lookup(const NNOut &o, const double *__restrict__ s64, int qrow, double qx, double qy,
+                                                   double qz, int wrow, double d2)
+{
+    double rx = 0.0, ry = 0.0, rz = 0.0;
+    if (o.nrm && wrow >= 0) {
+        rx = s64[3 * (int64_t)wrow];
+        ry = s64[3 * (int64_t)wrow + 1];
+        rz = s64[3 * (int64_t)wrow + 2];
+    }
+    emit_result(o, qrow, qx, qy, qz, wrow, d2, rx, ry, rz);
+}
+
+// ---- query jobs (pccm_grid.hip launches; pccm_brick.hip holds the LDS-brick kernel) ----------------------
+struct QueryJob {
+    const void *qrecs;          // cell-sorted queries of this job, [nq] (GridRec or Rec32: Grid::rec32)
+    const void *qbase;          // array the query cloud's cell starts index (qrecs = qbase + first position)
+    const uint32_t *qcs;        // query cloud's (or shard's) cell starts
+    int64_t nq, nchunks;        // nchunks = ceil(nq / 64)
+    const uint32_t *cs;         // searched cloud's cell starts (positions in srecs)
+    const void *srecs;          // combined record array
+    const double *s64;          // searched cloud's fp64 rows (emit_result_lookup)
+    int64_t row_base;           // first row of the shard (outputs are indexed row - row_base)
+    double slack32;             // fp32 rounding slack of inexact inputs (see pccm_brute.hip); 0 = both clouds fp32-exact
+    NNOut out;
+    void *tail;                 // queries ring 1 could not settle (same record type)
+    uint32_t *counters;         // [0] = queries handed to the exact full rescan (k2b_fallback), [1] = tail length
+    int32_t *flagged;           // ... their rows (relative to row_base) and fp32 filter thresholds
+    float *flag_thr;
+};
+
+struct QueryJobs {
+    QueryJob j[2];
+    int njobs;
+};
+
+constexpr int kMaxRing = 3;
+
+// distance from q to the nearest face of the cube [c-r, c+r]^3 that still has cells behind it
+__device__ __forceinline__ double face_bound(const GridGeom &g, double qx, double qy, double qz, int cx, int cy, int cz, int r)
+{
+    double L = INFINITY;
+    const double q[3] = {qx, qy, qz};
+    const int c[3] = {cx, cy, cz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (c[a] - r > 0) L = fmin(L, (q[a] - (g.org[a] + (double)(c[a] - r) * g.h[a])) - g.slack[a]);
+        if (c[a] + r < g.dim[a] - 1) L = fmin(L, ((g.org[a] + (double)(c[a] + r + 1) * g.h[a]) - q[a]) - g.slack[a]);
+    }
+    return L;
+}
+
+__device__ __forceinline__ bool settled_by(double L, double d)
+{
+    return (L == INFINITY) || (L > 0.0 && d < L * L * (1.0 - 0x1.0p-30));
+}
+
+// LDS-brick ring-1 kernel for Rec32 grids (pccm_brick.hip)
+int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self);
+bool brick_applicable(const GridGeom &g);
+
+}  // namespace pccm

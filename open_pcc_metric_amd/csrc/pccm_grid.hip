@@ -9,17 +9,19 @@
 // ties go to the smallest original row: results are bit-identical to the brute-force engine and to the
 // oracle.
 //
-// Data layout in HBM: GridRec = {double x, y, z; int32 row; pad} (32 B) for BOTH clouds in one array
-// (cloud A's records, then cloud B's), sorted by cell within each cloud, cells in x-fastest order, so
-// the 3 cells of one x-run are one contiguous range and a 3x3x3 neighbourhood is 9 ranges;
-// cell_start is uint32[2][ncells + 1] holding positions in the combined array.  Queries are processed
-// in cell-sorted order (the iterating cloud's own records, or a shard's rows sorted by the same cells).
+// Data layout in HBM: cell-sorted records of BOTH clouds in one array (cloud A's records, then cloud B's), cells in
+// x-fastest order, so the 3 cells of one x-run are one contiguous range and a 3x3x3 neighbourhood is 9 ranges.
+// Record = Rec32 {float x, y, z; int32 row} (16 B) when both clouds are fp32-exact, else GridRec
+// {double x, y, z; int32 row; pad} (32 B) (pccm_grid.h); cell_start is uint32[2][ncells + 1] holding positions in
+// the combined array.  Queries are processed in cell-sorted order (the iterating cloud's own records, or a
+// shard's rows sorted by the same cells).  Results leave as 32-byte records in row order (NNOut, pccm_grid.h).
 //
-// Launch structure (everything that exists per direction or per cloud is fused into one launch over
-// "jobs", because at these sizes the kernels are latency-bound and launches cost ~5 us each):
-//   build   k_grid_cells (cell id + rank by atomicAdd, both clouds) -> exclusive scan -> k_grid_scatter
+// Launch structure (everything that exists per direction or per cloud is fused into one launch over "jobs"):
+//   build   pccm_gridbuild.hip: bin count -> scan -> bin scatter -> bin sort (LDS atomics only)
 //   query   well-filled x-rows (volumetric float data):
-//             k_grid_query_coop (ring 1, fp32 in LDS, fp64 certification; both directions)
+//             fp32-exact clouds: k_brick_query (pccm_brick.hip; LDS brick, fp32 filter, fp64 certification,
+//               fused D2 projection; both directions)
+//             otherwise: k_grid_query_coop (per-wave staging, segment-local fp32)
 //             -> k_grid_finish: few unsettled queries one wave each (wave_tail), many one thread each
 //                (thread_search), rings 1..kMaxRing
 //           surfaces and integer lattices (decide_scale, use_coop):
@@ -31,244 +33,36 @@
 // point in a cell left of cell c lies below org + c*h up to a few ulps of the grid's size; the
 // kernels subtract that slack (g.slack[a]) from every face distance and compare with a strict
 // "<" after shrinking the bound by 2^-30, so a stop is never taken on a rounding coincidence.
-#include "pccm_internal.h"
+#include "pccm_grid.h"
 
 namespace pccm {
 
-constexpr int kMaxRing = 3;
 constexpr uint32_t kTailWaveMax = 16384;   // tails up to this many queries take the wave-per-query kernel
 
-struct GridGeom {
-    int dim[3];
-    double org[3], h[3], inv_h[3], slack[3];
-};
-
-__device__ __forceinline__ int cell_coord(double v, double org, double inv_h, int dim)
-{
-    double t = floor(__dmul_rn(__dsub_rn(v, org), inv_h));
-    t = t < 0.0 ? 0.0 : t;
-    const double top = (double)(dim - 1);
-    t = t > top ? top : t;
-    return (int)t;
-}
-
-__device__ __forceinline__ double gdist64(double qx, double qy, double qz, double rx, double ry, double rz)
-{
-    double dx = __dsub_rn(qx, rx), dy = __dsub_rn(qy, ry), dz = __dsub_rn(qz, rz);
-    double d = __dmul_rn(dx, dx);
-    d = __dadd_rn(d, __dmul_rn(dy, dy));
-    d = __dadd_rn(d, __dmul_rn(dz, dz));
-    return d;
-}
-
-__device__ __forceinline__ int rec_row(const double4 &a) { return (int)(__double_as_longlong(a.w) & 0xffffffffll); }
-
-// ---- build: cell id + rank (one atomic per point), scan, scatter (no atomics) ------------------------
-struct BuildJob {
-    const double *x64;   // [.][3]
-    int64_t row0, n;     // rows [row0, row0 + n)
-    uint32_t *cs;        // this job's cell counters / starts, [ncells + 1]
-};
-
-struct BuildJobs {
-    BuildJob j[2];
-    int njobs;
-    int64_t total;
-};
-
-__global__ __launch_bounds__(256) void k_grid_cells(BuildJobs jobs, GridGeom g, uint32_t *__restrict__ cell_of,
-                                                    uint32_t *__restrict__ rank)
+// per-cell histogram of one cloud (measure_occupancy: cell-edge decision, once per pair of clouds)
+__global__ __launch_bounds__(256) void k_cell_hist(const double *__restrict__ x64, int64_t n, GridGeom g, uint32_t *__restrict__ hist)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= jobs.total) return;
-    const int which = (jobs.njobs > 1 && i >= jobs.j[0].n) ? 1 : 0;
-    const BuildJob &J = jobs.j[which];
-    const int64_t li = which ? i - jobs.j[0].n : i;
-    const double *p = J.x64 + 3 * (J.row0 + li);
-    const int cx = cell_coord(p[0], g.org[0], g.inv_h[0], g.dim[0]);
-    const int cy = cell_coord(p[1], g.org[1], g.inv_h[1], g.dim[1]);
-    const int cz = cell_coord(p[2], g.org[2], g.inv_h[2], g.dim[2]);
-    const uint32_t c = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
-    cell_of[i] = c;
-    rank[i] = atomicAdd(&J.cs[c], 1u);
-}
-
-__global__ __launch_bounds__(256) void k_grid_scatter(BuildJobs jobs, const uint32_t *__restrict__ cell_of,
-                                                      const uint32_t *__restrict__ rank, GridRec *__restrict__ recs)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= jobs.total) return;
-    const int which = (jobs.njobs > 1 && i >= jobs.j[0].n) ? 1 : 0;
-    const BuildJob &J = jobs.j[which];
-    const int64_t li = which ? i - jobs.j[0].n : i;
-    const double *p = J.x64 + 3 * (J.row0 + li);
-    const uint32_t pos = J.cs[cell_of[i]] + rank[i];
-    double4 r;
-    r.x = p[0]; r.y = p[1]; r.z = p[2];
-    r.w = __longlong_as_double((long long)(uint32_t)(J.row0 + li));
-    *reinterpret_cast<double4 *>(&recs[pos]) = r;
-}
-
-// Exclusive prefix sum of uint32 data[0..m) in place, ONE pass over the data (decoupled look-back): a tile of
-// 4096 counters per workgroup; tiles are handed out by an atomic ticket, so every predecessor of a running tile
-// is itself running or done and the look-back cannot starve.  Every tile publishes (status, value) in one
-// 64-bit word -- first its own total (status 1), then, once the totals of all earlier tiles are known, its
-// inclusive prefix (status 2); wave 0 of the tile looks back 64 predecessors at a time.  For surface-like
-// clouds the grid has ~20 cells per point and this scan, not the points, is what the build moves through HBM:
-// one read and one write of the counters instead of two each.
-// `state` = [ntiles] words followed by the ticket counter, all zero on entry (sort_by_cell's memset covers it).
-constexpr int kLbItems = 64;
-constexpr int kLbTile = 256 * kLbItems;
-
-static int64_t scan_tiles(int64_t m) { return (m + kLbTile - 1) / kLbTile; }
-// bytes a counter array of m entries needs including the scan's state behind it
-static size_t counters_bytes(int64_t m) { return (size_t)((m + 1) / 2 * 2) * sizeof(uint32_t) + (size_t)(scan_tiles(m) + 1) * 8; }
-static unsigned long long *scan_state(uint32_t *data, int64_t m) { return reinterpret_cast<unsigned long long *>(data + (m + 1) / 2 * 2); }
-
-__global__ __launch_bounds__(256) void k_scan_lookback(uint32_t *__restrict__ data, int64_t m, unsigned long long *__restrict__ state,
-                                                       int64_t ntiles)
-{
-    __shared__ uint32_t s_tile, s_prefix, wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_tile = (uint32_t)atomicAdd(&state[ntiles], 1ull);
-    __syncthreads();
-    const int64_t tile = s_tile;
-    const int64_t base = tile * kLbTile + (int64_t)tid * kLbItems;
-    uint32_t v[kLbItems], tot = 0;
-    if (base + kLbItems <= m) {
-#pragma unroll
-        for (int k = 0; k < kLbItems; k += 4) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(&data[base + k]);
-            v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kLbItems; ++k) v[k] = (base + k < m) ? data[base + k] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < kLbItems; ++k) tot += v[k];
-    uint32_t inc = tot;                                   // inclusive scan of thread totals in the wave
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int k = 0; k < w; ++k) woff += wsum[k];
-    const uint32_t agg = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (w == 0) {
-        if (lane == 0)
-            __hip_atomic_store(&state[tile], ((tile == 0 ? 2ull : 1ull) << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        int64_t p = tile - 1;
-        while (p >= 0) {
-            const int64_t idx = p - lane;
-            const unsigned long long st = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                   : (2ull << 32);          // before the first tile: prefix 0
-            const uint32_t status = (uint32_t)(st >> 32), val = (uint32_t)st;
-            const unsigned long long incl = __ballot(status == 2u), empty = __ballot(status == 0u);
-            const int first = incl ? __ffsll((long long)incl) - 1 : 64;     // nearest predecessor with a full prefix
-            const unsigned long long nearer = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
-            if (empty & nearer) {                                            // someone nearer has not published yet
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-            uint32_t part = (lane <= first) ? val : 0u;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            excl += part;
-            if (first < 64) break;
-            p -= 64;
-        }
-        if (lane == 0) {
-            if (tile > 0) __hip_atomic_store(&state[tile], (2ull << 32) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = excl;
-        }
-    }
-    __syncthreads();
-    uint32_t run = s_prefix + woff + inc - tot;
-    if (base + kLbItems <= m) {
-#pragma unroll
-        for (int k = 0; k < kLbItems; k += 4) {
-            uint4 q;
-            q.x = run; run += v[k];
-            q.y = run; run += v[k + 1];
-            q.z = run; run += v[k + 2];
-            q.w = run; run += v[k + 3];
-            *reinterpret_cast<uint4 *>(&data[base + k]) = q;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kLbItems; ++k) {
-            if (base + k < m) data[base + k] = run;
-            run += v[k];
-        }
-    }
-}
-
-static int exclusive_scan(pccm_ctx *ctx, uint32_t *data, int64_t m)
-{
-    const int64_t nt = scan_tiles(m);
-    hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nt), dim3(256), 0, ctx->stream, data, m, scan_state(data, m), nt);
-    PCCM_HIP(hipGetLastError());
-    return PCCM_OK;
-}
-
-// counting sort by cell: cs_all = the jobs' counters, contiguous, [cs_len]; on return they hold the
-// exclusive starts (positions in recs, running across the jobs) and recs is filled
-static int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, uint32_t *cs_all, int64_t cs_len,
-                        GridRec *recs)
-{
-    int rc;
-    if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)jobs.total * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->g_rank, (size_t)jobs.total * sizeof(uint32_t)))) return rc;
-    uint32_t *cell_of = (uint32_t *)ctx->g_cell_of.p, *rank = (uint32_t *)ctx->g_rank.p;
-    PCCM_HIP(hipMemsetAsync(cs_all, 0, counters_bytes(cs_len), ctx->stream));      // counters + the scan's state behind them
-    dim3 grid((unsigned)((jobs.total + 255) / 256));
-    hipLaunchKernelGGL(k_grid_cells, grid, dim3(256), 0, ctx->stream, jobs, g, cell_of, rank);
-    if ((rc = exclusive_scan(ctx, cs_all, cs_len))) return rc;
-    hipLaunchKernelGGL(k_grid_scatter, grid, dim3(256), 0, ctx->stream, jobs, (const uint32_t *)cell_of, (const uint32_t *)rank, recs);
-    PCCM_HIP(hipGetLastError());
-    return PCCM_OK;
+    if (i >= n) return;
+    const double *p = x64 + 3 * i;
+    atomicAdd(&hist[cell_linear(g, p[0], p[1], p[2])], 1u);
 }
 
 // ---- query --------------------------------------------------------------------------------------------
-struct QueryJob {
-    const GridRec *qrecs;       // cell-sorted queries
-    int64_t nq, nchunks;        // nchunks = ceil(nq / 64)
-    const uint32_t *cs;         // searched cloud's cell starts (positions in srecs)
-    const GridRec *srecs;       // combined record array
-    int64_t row_base;           // first row of the shard (outputs are indexed row - row_base)
-    double slack32;             // fp32 rounding slack of inexact inputs (see pccm_brute.hip); 0 = both clouds fp32-exact
-    int32_t *idx_out;
-    double *d2_out;
-    GridRec *tail;              // queries ring 1 could not settle
-    uint32_t *counters;         // [0] = queries handed to the exact full rescan (k2b_fallback), [1] = tail length
-    int32_t *flagged;           // ... their rows (relative to row_base) and fp32 filter thresholds
-    float *flag_thr;
-};
-
-struct QueryJobs {
-    QueryJob j[2];
-    int njobs;
-};
-
+// QueryJob / QueryJobs / NNOut: pccm_grid.h.  Every kernel below is templated on the record type of the grid
+// (GridRec: fp64 positions; Rec32: fp32-exact clouds, half the bytes per candidate).
 struct Best {
     double d;
     int idx;
 };
 
-__device__ __forceinline__ void consider(const double4 &a, double qx, double qy, double qz, int qrow, bool self, Best &b)
+__device__ __forceinline__ void consider(const P3 &a, double qx, double qy, double qz, int qrow, bool self, Best &b)
 {
-    const int row = rec_row(a);
     const double d = gdist64(qx, qy, qz, a.x, a.y, a.z);
-    bool better = d < b.d || (d == b.d && row < b.idx);
-    if (self) better = better && (row != qrow);
+    bool better = d < b.d || (d == b.d && a.row < b.idx);
+    if (self) better = better && (a.row != qrow);
     b.d = better ? d : b.d;
-    b.idx = better ? row : b.idx;
+    b.idx = better ? a.row : b.idx;
 }
 
 // Scan records [s, e) kBatch at a time: the loads of a batch are independent and issued together
@@ -276,39 +70,17 @@ __device__ __forceinline__ void consider(const double4 &a, double qx, double qy,
 // e-1, and re-evaluating a record is harmless because the lexicographic min is idempotent.
 constexpr int kBatch = 4;
 
-template <bool SELF>
-__device__ __forceinline__ void scan_range(const GridRec *__restrict__ recs, uint32_t s, uint32_t e, double qx, double qy,
+template <typename REC, bool SELF>
+__device__ __forceinline__ void scan_range(const REC *__restrict__ recs, uint32_t s, uint32_t e, double qx, double qy,
                                            double qz, int qrow, Best &b)
 {
     for (uint32_t p = s; p < e; p += kBatch) {
-        double4 a[kBatch];
+        P3 a[kBatch];
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const uint32_t pj = (p + j < e) ? p + j : e - 1;
-            a[j] = *reinterpret_cast<const double4 *>(&recs[pj]);   // x y z | (row, pad)
-        }
+        for (int j = 0; j < kBatch; ++j) a[j] = load_rec(recs, (p + j < e) ? p + j : e - 1);
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) consider(a[j], qx, qy, qz, qrow, SELF, b);
     }
-}
-
-// distance from q to the nearest face of the cube [c-r, c+r]^3 that still has cells behind it
-__device__ __forceinline__ double face_bound(const GridGeom &g, double qx, double qy, double qz, int cx, int cy, int cz, int r)
-{
-    double L = INFINITY;
-    const double q[3] = {qx, qy, qz};
-    const int c[3] = {cx, cy, cz};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        if (c[a] - r > 0) L = fmin(L, (q[a] - (g.org[a] + (double)(c[a] - r) * g.h[a])) - g.slack[a]);
-        if (c[a] + r < g.dim[a] - 1) L = fmin(L, ((g.org[a] + (double)(c[a] + r + 1) * g.h[a]) - q[a]) - g.slack[a]);
-    }
-    return L;
-}
-
-__device__ __forceinline__ bool settled_by(double L, double d)
-{
-    return (L == INFINITY) || (L > 0.0 && d < L * L * (1.0 - 0x1.0p-30));
 }
 
 // A query kMaxRing rings could not settle (isolated outliers, clouds that overlap only in part) goes on the
@@ -326,29 +98,29 @@ __device__ __forceinline__ void defer_rescan(const QueryJob &J, int qrow, double
     J.flag_thr[pos] = tf;
 }
 
-// ---- per-thread ring search: the long-tail kernel (and the whole query when PCCM_GRID_COOP=0) --------------
+// ---- per-thread ring search: the long-tail kernel, and the whole query for surfaces and lattices ----------
 // One query per thread, rings 1..kMaxRing.  from_tail: the queries are the job's tail list and the kernel
 // only runs when that list is too long for wave_tail.
-template <bool SELF>
+template <typename REC, bool SELF>
 __device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridGeom &g, int from_tail)
 {
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
     for (int jb = 0; jb < jobs.njobs; ++jb) {
         const QueryJob &J = jobs.j[jb];
-        const GridRec *__restrict__ qrecs = from_tail ? J.tail : J.qrecs;
+        const REC *__restrict__ qrecs = (const REC *)(from_tail ? J.tail : J.qrecs);
         int64_t nq = J.nq;
         if (from_tail) {
             nq = (int64_t)J.counters[1];
             if (nq <= (int64_t)kTailWaveMax) continue;      // short tail: wave_tail handled it
         }
         const uint32_t *__restrict__ cell_start = J.cs;
-        const GridRec *__restrict__ srecs = J.srecs;
+        const REC *__restrict__ srecs = (const REC *)J.srecs;
         for (int64_t t0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); t0 < nq; t0 += (int64_t)gridDim.x * 256) {
             const int64_t t = t0 + (threadIdx.x & 63);
-            const bool live = t < nq;                        // dead lanes ride along (wave-cooperative tail below)
-            const double4 qa = *reinterpret_cast<const double4 *>(&qrecs[live ? t : nq - 1]);
+            const bool live = t < nq;
+            const P3 qa = load_rec(qrecs, (uint32_t)(live ? t : nq - 1));
             const double qx = qa.x, qy = qa.y, qz = qa.z;
-            const int qrow = rec_row(qa);
+            const int qrow = qa.row;
             const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
             const int cy = cell_coord(qy, g.org[1], g.inv_h[1], dimy);
             const int cz = cell_coord(qz, g.org[2], g.inv_h[2], dimz);
@@ -370,7 +142,7 @@ __device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridG
                     re[k] = in ? c : 0u;
                 }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) scan_range<SELF>(srecs, rs[k], re[k], qx, qy, qz, qrow, b);
+                for (int k = 0; k < 9; ++k) scan_range<REC, SELF>(srecs, rs[k], re[k], qx, qy, qz, qrow, b);
             }
             for (int r = 1; r <= kMaxRing && !done; ++r) {
                 if (r > 1) {
@@ -382,12 +154,12 @@ __device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridG
                         for (int y = y0; y <= y1; ++y) {
                             const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
                             if (zface || y == cy - r || y == cy + r) {
-                                scan_range<SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
+                                scan_range<REC, SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
                             } else {                                    // interior of the shell: only the two end cells
                                 if (cx - r >= 0)
-                                    scan_range<SELF>(srecs, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, qrow, b);
+                                    scan_range<REC, SELF>(srecs, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, qrow, b);
                                 if (cx + r <= dimx - 1)
-                                    scan_range<SELF>(srecs, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, qrow, b);
+                                    scan_range<REC, SELF>(srecs, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, qrow, b);
                             }
                         }
                     }
@@ -396,43 +168,43 @@ __device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridG
             }
             if (done && live) {
                 if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }   // SELF on a one-point cloud (host handles it earlier)
-                J.idx_out[qrow - J.row_base] = b.idx;
-                J.d2_out[qrow - J.row_base] = b.d;
+                emit_result_lookup(J.out, J.s64, qrow, qx, qy, qz, b.idx, b.d);
             }
             if (!done) defer_rescan(J, qrow, b.d);           // still open after kMaxRing rings
         }
     }
 }
 
-// ---- cooperative ring-1 kernel ---------------------------------------------------------------------
+// ---- cooperative ring-1 kernel for clouds that are NOT fp32-exact (GridRec grids) ----------------------------
+// (fp32-exact pairs take the LDS-brick kernel of pccm_brick.hip instead.)
 // A wave owns 64 consecutive queries of the cell-sorted list and works on one *segment* at a time: the
 // queries that share an x-row of cells (same cy, cz; at most kSegWidth cells wide).  For the nine x-runs
 // around that row the wave
 //   1. fetches all cell bounds with nine coalesced loads issued together (lane i reads
 //      cell_start[x_lo + i]) and hands every lane its own [s, e) per run by shuffle,
 //   2. stages the runs' records into LDS as fp32 SoA (x | y | z [| row]) with coalesced 32-byte-per-lane
-//      loads -- every record is fetched once per wave instead of once per lane (the per-thread kernel is
-//      bound by the L1/TA address path: each of its loads touches ~30 cache lines per wave),
+//      loads -- every record is fetched once per wave instead of once per lane,
 //   3. lets every lane scan only its own candidates from LDS in fp32 (same-cell lanes broadcast),
 //      tracking best d32, its record position and the second-best d32 -- no fp64, no branches,
 //   4. certifies like k2_refine: if the second-best d32 is above thr(best d32) the fp32 winner is the
 //      unique fp64 winner, whose exact d2 is then computed once from its fp64 record.
+// fp32 works on coordinates relative to the segment's corner (subtracted in fp64 from queries and candidates
+// alike, so it cancels in exact arithmetic): the rounding of the fp64 -> fp32 conversion scales with the
+// local extent instead of the coordinate magnitude (geo-referenced clouds: |x| ~ 1e6 m at mm resolution).
 // Queries that cannot be certified (near ties) or whose ring-1 result does not satisfy the stop rule go
 // to `tail`.  Integer-valued clouds, where exact ties are the rule, never come here (use_coop).
 constexpr int kCap = 384;         // fp32 records staged per wave (4.5 KB); more -> several windows
 constexpr int kSegWidth = 61;     // + 3 bounds = 64 lanes
 constexpr float kBigF = 3.0e38f;
 
-template <bool SELF, bool SHIFT>
+template <bool SELF>
 __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeom g)
 {
     __shared__ float lx[4][kCap + 1], ly[4][kCap + 1], lz[4][kCap + 1];
     __shared__ int lrow[SELF ? 4 : 1][SELF ? kCap + 1 : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // XCD-aware order: workgroups b, b+8, b+16, ... share an XCD (and its 4 MB L2), so give every XCD one
-    // contiguous eighth of the cell-sorted chunk list = one slab of the grid.  The nine x-runs a chunk
-    // stages are shared with the chunks of the neighbouring rows; with this mapping those run on the same
-    // XCD and hit its L2 instead of each XCD pulling its own copy from the Infinity Cache.  Speed only.
+    // contiguous eighth of the cell-sorted chunk list = one slab of the grid.  Speed only.
     const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t bq = nblk >> 3, br = nblk & 7u;
     const uint32_t vb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + slot;
@@ -443,13 +215,13 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
     const int64_t nq = J.nq;
     if (chunk * 64 >= nq) return;                       // wave-uniform
     const uint32_t *__restrict__ cell_start = J.cs;
-    const GridRec *__restrict__ srecs = J.srecs;
+    const GridRec *__restrict__ srecs = (const GridRec *)J.srecs;
     const int64_t t = chunk * 64 + lane;
     const bool valid = t < nq;
-    const double4 qa = *reinterpret_cast<const double4 *>(&J.qrecs[valid ? t : nq - 1]);
+    const double4 qa = *reinterpret_cast<const double4 *>(&((const GridRec *)J.qrecs)[valid ? t : nq - 1]);
     const double qx = qa.x, qy = qa.y, qz = qa.z;
-    float fx = (float)qx, fy = (float)qy, fz = (float)qz;
-    const int qrow = rec_row(qa);
+    float fx, fy, fz;
+    const int qrow = (int)(__double_as_longlong(qa.w) & 0xffffffffll);
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
     const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
     const int cy = cell_coord(qy, g.org[1], g.inv_h[1], dimy);
@@ -469,19 +241,12 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
         const int x_lo = max(xa - 1, 0);
         const int x_hi = min(xb + 2, dimx);             // index of the last bound needed
         const int my_s = (max(cx - 1, 0) - x_lo) & 63, my_e = (min(cx + 2, dimx) - x_lo) & 63;
-        // SHIFT (some input is not fp32-exact): fp32 works on coordinates relative to the segment's corner, so the
-        // rounding of the fp64 -> fp32 conversion scales with the local extent instead of the coordinate magnitude
-        // (geo-referenced clouds: |x| ~ 1e6 m at mm resolution).  The same origin is subtracted from queries and
-        // candidates, in fp64, so it cancels in exact arithmetic.
-        double ox = 0.0, oy = 0.0, oz = 0.0;
-        if (SHIFT) {
-            ox = g.org[0] + (double)x_lo * g.h[0];
-            oy = g.org[1] + (double)cyl * g.h[1];
-            oz = g.org[2] + (double)czl * g.h[2];
-            fx = (float)(qx - ox);
-            fy = (float)(qy - oy);
-            fz = (float)(qz - oz);
-        }
+        const double ox = g.org[0] + (double)x_lo * g.h[0];
+        const double oy = g.org[1] + (double)cyl * g.h[1];
+        const double oz = g.org[2] + (double)czl * g.h[2];
+        fx = (float)(qx - ox);
+        fy = (float)(qy - oy);
+        fz = (float)(qz - oz);
 
         // per run k: wave-uniform S (first record), off (start in the flattened candidate list) in
         // SGPRs; per lane only the flat start and the length of its own three-cell range
@@ -512,10 +277,10 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
                 const uint32_t bnd = off[k + 1] < W1 ? off[k + 1] : W1;
                 for (uint32_t f = a + lane; f < bnd; f += 64) {
                     const double4 r = *reinterpret_cast<const double4 *>(&srecs[S[k] + (f - off[k])]);
-                    lx[w][f - W0] = (float)(SHIFT ? r.x - ox : r.x);
-                    ly[w][f - W0] = (float)(SHIFT ? r.y - oy : r.y);
-                    lz[w][f - W0] = (float)(SHIFT ? r.z - oz : r.z);
-                    if (SELF) lrow[w][f - W0] = rec_row(r);
+                    lx[w][f - W0] = (float)(r.x - ox);
+                    ly[w][f - W0] = (float)(r.y - oy);
+                    lz[w][f - W0] = (float)(r.z - oz);
+                    if (SELF) lrow[w][f - W0] = (int)(__double_as_longlong(r.w) & 0xffffffffll);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -567,25 +332,19 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
             // input-rounding slack: a candidate that can win or tie in fp64 lies within d(best) of the query, so its
             // local coordinates are bounded by the query's plus that distance; each conversion is off by at most
             // 2^-24 of the coordinate, 2^-20 * (|q|_inf + d) covers the two points involved with room to spare
-            double slack = 0.0;
-            if (SHIFT) slack = ((double)fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) + sqrt((double)best)) * 0x1.0p-20;
+            const double slack = ((double)fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) + sqrt((double)best)) * 0x1.0p-20;
             const double tq = sqrt((double)best) * (1.0 + 0x1.0p-20) + slack;
             const double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
             bool settled = false;
-            double d64 = 0.0;
-            int wrow = -1;
             if (bestpos != 0xffffffffu && (double)second > thr) {
-                const double4 r = *reinterpret_cast<const double4 *>(&srecs[bestpos]);
-                d64 = gdist64(qx, qy, qz, r.x, r.y, r.z);
-                wrow = rec_row(r);
+                const P3 r = load_rec(srecs, bestpos);
+                const double d64 = gdist64(qx, qy, qz, r.x, r.y, r.z);
                 settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
+                if (settled) emit_result(J.out, qrow, qx, qy, qz, r.row, d64, r.x, r.y, r.z);
             }
-            if (settled) {
-                J.idx_out[qrow - J.row_base] = wrow;
-                J.d2_out[qrow - J.row_base] = d64;
-            } else {
+            if (!settled) {
                 const uint32_t pos = atomicAdd(&J.counters[1], 1u);
-                *reinterpret_cast<double4 *>(&J.tail[pos]) = qa;
+                *reinterpret_cast<double4 *>(&((GridRec *)J.tail)[pos]) = qa;
             }
         }
         pending &= ~seg;
@@ -599,8 +358,8 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
 // bounds load plus a few batched record loads; the lexicographic (d2, row) minimum is reduced across the
 // wave and the stop rule is evaluated wave-uniformly.  Rings already scanned are simply scanned again
 // (the minimum is idempotent).  Long tails (lattice data, where exact ties defeat the fp32
-// certification) go through k_grid_query instead, which has the parallelism then.
-template <bool SELF>
+// certification) go through thread_search instead, which has the parallelism then.
+template <typename REC, bool SELF>
 __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom &g)
 {
     const int lane = threadIdx.x & 63;
@@ -609,13 +368,13 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
     for (int jb = 0; jb < jobs.njobs; ++jb) {
         const QueryJob &J = jobs.j[jb];
         const uint32_t count = J.counters[1];
-        if (count > kTailWaveMax) continue;                 // long tail: k_grid_query handles it
+        if (count > kTailWaveMax) continue;                 // long tail: thread_search handles it
         const uint32_t *__restrict__ cell_start = J.cs;
-        const GridRec *__restrict__ srecs = J.srecs;
+        const REC *__restrict__ srecs = (const REC *)J.srecs;
         for (uint32_t qi = wave0; qi < count; qi += nwaves) {
-            const double4 qa = *reinterpret_cast<const double4 *>(&J.tail[qi]);   // wave-uniform
+            const P3 qa = load_rec((const REC *)J.tail, qi);   // wave-uniform
             const double qx = qa.x, qy = qa.y, qz = qa.z;
-            const int qrow = rec_row(qa);
+            const int qrow = qa.row;
             const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
             const int cy = cell_coord(qy, g.org[1], g.inv_h[1], dimy);
             const int cz = cell_coord(qz, g.org[2], g.inv_h[2], dimz);
@@ -630,7 +389,7 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
                     if (z >= 0 && z < dimz && y >= 0 && y < dimy) {
                         const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
                         const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
-                        scan_range<SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
+                        scan_range<REC, SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
                     }
                 }
                 double wm = b.d;
@@ -649,27 +408,26 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
             }
             if (lane == 0) {
                 if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }
-                J.idx_out[qrow - J.row_base] = b.idx;
-                J.d2_out[qrow - J.row_base] = b.d;
+                emit_result_lookup(J.out, J.s64, qrow, qx, qy, qz, b.idx, b.d);
             }
         }
     }
 }
 
-// one launch finishes whatever the cooperative kernel left open: short tails wave-per-query, long tails
+// one launch finishes whatever the ring-1 kernel left open: short tails wave-per-query, long tails
 // thread-per-query (each checks the tail length on the device and does nothing when it is not its case)
-template <bool SELF>
+template <typename REC, bool SELF>
 __global__ __launch_bounds__(256) void k_grid_finish(QueryJobs jobs, GridGeom g)
 {
-    wave_tail<SELF>(jobs, g);
-    thread_search<SELF>(jobs, g, 1);
+    wave_tail<REC, SELF>(jobs, g);
+    thread_search<REC, SELF>(jobs, g, 1);
 }
 
-// the whole query by the per-thread search (PCCM_GRID_COOP=0; A/B reference for the cooperative kernel)
-template <bool SELF>
+// the whole query by the per-thread search (surfaces, lattices; PCCM_GRID_COOP=0)
+template <typename REC, bool SELF>
 __global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g)
 {
-    thread_search<SELF>(jobs, g, 0);
+    thread_search<REC, SELF>(jobs, g, 0);
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -849,19 +607,11 @@ static int measure_occupancy(pccm_ctx *ctx, const Cloud &c, double scale, Occupa
     choose_geometry(ctx, g, ncells, scale);
     int rc;
     if ((rc = ensure(ctx, ctx->g_hist, (size_t)(ncells + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)c.n * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->g_rank, (size_t)c.n * sizeof(uint32_t)))) return rc;
     uint32_t *hist = (uint32_t *)ctx->g_hist.p;
     unsigned long long *counter = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(hist, 0, (size_t)(ncells + 1) * sizeof(uint32_t), ctx->stream));
     PCCM_HIP(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    BuildJobs bj;
-    bj.njobs = 1;
-    bj.j[0] = {c.xyz64, 0, c.n, hist};
-    bj.j[1] = bj.j[0];
-    bj.total = c.n;
-    hipLaunchKernelGGL(k_grid_cells, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream, bj, g,
-                       (uint32_t *)ctx->g_cell_of.p, (uint32_t *)ctx->g_rank.p);
+    hipLaunchKernelGGL(k_cell_hist, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)c.xyz64, c.n, g, hist);
     hipLaunchKernelGGL(k_count_occupied, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)hist, ncells, counter);
     unsigned long long h[2] = {0, 0};
     PCCM_HIP(hipMemcpyAsync(h, counter, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1042,12 +792,21 @@ int grid_decide(pccm_ctx *ctx, bool *hostile)
     return PCCM_OK;
 }
 
-// (re)build the combined grid when either cloud changed or the caches were dropped
-static int ensure_grid(pccm_ctx *ctx)
+// record layout for the current pair: Rec32 when both clouds are fp32-exact (PCCM_GRID_REC64=1 forces GridRec, for A/B runs)
+static bool pair_rec32(const pccm_ctx *ctx)
+{
+    static const bool force64 = [] { const char *e = getenv("PCCM_GRID_REC64"); return e && e[0] == '1'; }();
+    return !force64 && ctx->cloud[0].exact32 && ctx->cloud[1].exact32;
+}
+
+// (re)build the combined grid when either cloud changed, the caches were dropped or the record layout asked for
+// differs from the built one (need64: a caller that reads GridRec records, pccm_normals.hip)
+static int ensure_grid(pccm_ctx *ctx, bool need64 = false)
 {
     Grid &gr = ctx->grid;
     const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
-    if (gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p) return PCCM_OK;
+    const bool rec32 = !need64 && pair_rec32(ctx);
+    if (gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p && gr.rec32 == rec32) return PCCM_OK;
     int rc0 = decide_scale(ctx, key);
     if (rc0) return rc0;
     ProfScope ps(ctx, PCCM_K_GRID_BUILD);
@@ -1056,15 +815,15 @@ static int ensure_grid(pccm_ctx *ctx)
     choose_geometry(ctx, g, ncells, gr.scale);
     const int64_t n0 = ctx->cloud[0].n, n1 = ctx->cloud[1].n;
     int rc;
-    if ((rc = ensure(ctx, gr.cell_start, counters_bytes(2 * (ncells + 1))))) return rc;
-    if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;
+    if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;   // either layout fits
     uint32_t *cs = (uint32_t *)gr.cell_start.p;
     BuildJobs jobs;
     jobs.njobs = 2;
-    jobs.j[0] = {ctx->cloud[0].xyz64, 0, n0, cs};
-    jobs.j[1] = {ctx->cloud[1].xyz64, 0, n1, cs + ncells + 1};
+    jobs.j[0] = {ctx->cloud[0].xyz64, (const float *)ctx->cloud[0].xyz32, 0, n0, cs};
+    jobs.j[1] = {ctx->cloud[1].xyz64, (const float *)ctx->cloud[1].xyz32, 0, n1, cs + ncells + 1};
     jobs.total = n0 + n1;
-    if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, cs, 2 * (ncells + 1), (GridRec *)gr.recs.p))) return rc;
+    if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, ncells, gr.recs.p, rec32))) return rc;
     for (int a = 0; a < 3; ++a) {
         gr.dim[a] = g.dim[a];
         gr.org[a] = g.org[a];
@@ -1075,6 +834,7 @@ static int ensure_grid(pccm_ctx *ctx)
     gr.n[0] = n0;
     gr.n[1] = n1;
     gr.key = key;
+    gr.rec32 = rec32;
     return PCCM_OK;
 }
 
@@ -1082,14 +842,15 @@ static int ensure_grid(pccm_ctx *ctx)
 // (k2b_fallback): fine for stray points, ruinous when a whole region of one cloud has no counterpart
 // (clouds that overlap only in part, or not at all).  Counted once per pair of clouds on the freshly
 // built grid; beyond ~3 % of the queries the brute-force engine is the cheaper way to be exact.
-__global__ __launch_bounds__(256) void k_count_isolated(const GridRec *__restrict__ qrecs, int64_t nq,
+template <typename REC>
+__global__ __launch_bounds__(256) void k_count_isolated(const REC *__restrict__ qrecs, int64_t nq,
                                                         const uint32_t *__restrict__ cs, GridGeom g,
                                                         unsigned long long *__restrict__ out)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool isolated = false;
     if (t < nq) {
-        const double4 qa = *reinterpret_cast<const double4 *>(&qrecs[t]);
+        const P3 qa = load_rec(qrecs, (uint32_t)t);
         const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
         const int cx = cell_coord(qa.x, g.org[0], g.inv_h[0], dimx);
         const int cy = cell_coord(qa.y, g.org[1], g.inv_h[1], dimy);
@@ -1125,13 +886,17 @@ static int check_isolation(pccm_ctx *ctx)
     const GridGeom g = geom_of(gr);
     unsigned long long *counter = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    const GridRec *recs = (const GridRec *)gr.recs.p;
     const uint32_t *cs = (const uint32_t *)gr.cell_start.p;
     for (int ii = 0; ii < 2; ++ii) {                       // queries of cloud ii against the cells of the other cloud
         const int64_t nq = gr.n[ii];
         if (nq <= 0 || gr.n[1 - ii] <= 0) continue;
-        hipLaunchKernelGGL(k_count_isolated, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
-                           recs + (ii ? gr.n[0] : 0), nq, cs + (ii ? 0 : gr.ncells + 1), g, counter + ii);
+        dim3 grid((unsigned)((nq + 255) / 256));
+        if (gr.rec32)
+            hipLaunchKernelGGL((k_count_isolated<Rec32>), grid, dim3(256), 0, ctx->stream,
+                               (const Rec32 *)gr.recs.p + (ii ? gr.n[0] : 0), nq, cs + (ii ? 0 : gr.ncells + 1), g, counter + ii);
+        else
+            hipLaunchKernelGGL((k_count_isolated<GridRec>), grid, dim3(256), 0, ctx->stream,
+                               (const GridRec *)gr.recs.p + (ii ? gr.n[0] : 0), nq, cs + (ii ? 0 : gr.ncells + 1), g, counter + ii);
     }
     unsigned long long h[2] = {0, 0};
     PCCM_HIP(hipMemcpyAsync(h, counter, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1157,6 +922,32 @@ int grid_prefers_brute(pccm_ctx *ctx, bool *yes)
     return PCCM_OK;
 }
 
+// Is the D2 projection of direction `dir` fused into the search?  (pccm_nn_fuse; decided per call, never an error:
+// a request that cannot be honoured -- no normals, row-indexed normals out of range -- simply stays unfused and the
+// reduction falls back to the separate point kernel, which reports the reference's IndexError)
+static int fused_mode(const pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se)
+{
+    if (dir == PCCM_DIR_SELF) return -1;
+    const int mode = ctx->fuse_mode[dir];
+    if (mode != PCCM_NORMAL_ROW && mode != PCCM_NORMAL_NEIGHBOUR) return -1;
+    if (se.n_nrm <= 0) return -1;
+    if (mode == PCCM_NORMAL_ROW && it.n > se.n_nrm) return -1;      // the whole cloud, not the shard: ranks agree
+    if (mode == PCCM_NORMAL_NEIGHBOUR && se.n_nrm != se.n) return -1;
+    return mode;
+}
+
+template <typename REC>
+static void launch_queries(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, bool per_thread, dim3 grid)
+{
+    if (per_thread) {
+        if (self) hipLaunchKernelGGL((k_grid_query<REC, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+        else hipLaunchKernelGGL((k_grid_query<REC, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    } else {
+        if (self) hipLaunchKernelGGL((k_grid_finish<REC, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+        else hipLaunchKernelGGL((k_grid_finish<REC, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    }
+}
+
 // Exact 1-NN for `ndirs` directions (LEFT and RIGHT fused into the same launches when both are asked for).
 int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
 {
@@ -1165,7 +956,8 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
     const Grid &gr = ctx->grid;
     const GridGeom g = geom_of(gr);
     const uint32_t *cs_all = (const uint32_t *)gr.cell_start.p;
-    const GridRec *recs_all = (const GridRec *)gr.recs.p;
+    const char *recs_all = (const char *)gr.recs.p;
+    const size_t rsz = gr.rec32 ? sizeof(Rec32) : sizeof(GridRec);
 
     QueryJobs normal, selfj;
     normal.njobs = 0;
@@ -1195,11 +987,15 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         if ((rc = ensure(ctx, res.tail, (size_t)nq * sizeof(GridRec)))) return rc;
         QueryJob J;
         if (res.begin == 0 && res.end == it.n) {
-            J.qrecs = recs_all + (ii ? gr.n[0] : 0);       // whole cloud: its own cell-sorted records
+            J.qrecs = recs_all + (size_t)(ii ? gr.n[0] : 0) * rsz;   // whole cloud: its own cell-sorted records
+            J.qbase = recs_all;
+            J.qcs = cs_all + (ii ? gr.ncells + 1 : 0);
         } else {
             // shard: its rows are sorted by the same cells into the shared shard-record buffer (below, one
-            // counting sort for all directions of this call); remember where this direction's slice starts
+            // counting sort for up to two directions of this call); remember where this direction's slice starts
             J.qrecs = nullptr;
+            J.qbase = nullptr;
+            J.qcs = nullptr;
             shard_dirs[nshard] = dir;
             shard_off[nshard] = shard_total;
             shard_total += nq;
@@ -1211,11 +1007,18 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         J.nchunks = (nq + 63) / 64;
         J.cs = cs_all + (si ? gr.ncells + 1 : 0);
         J.srecs = recs_all;
+        J.s64 = se.xyz64;
         J.row_base = res.begin;
         J.slack32 = exact ? 0.0 : maxabs * 0x1.0p-20;
-        J.idx_out = res.idx;
-        J.d2_out = res.d2;
-        J.tail = (GridRec *)res.tail.p;
+        const int fm = fused_mode(ctx, dir, it, se);
+        J.out.rec = (double4 *)res.rec.p;
+        J.out.nrm = fm >= 0 ? se.nrm64 : nullptr;
+        J.out.row_base = res.begin;
+        J.out.normal_mode = fm >= 0 ? fm : PCCM_NORMAL_ROW;
+        res.fused_mode = fm;
+        res.rec_valid = true;
+        res.plain_valid = false;
+        J.tail = res.tail.p;
         J.counters = res.nflag_dev;                         // [0] full rescans, [1] tail length
         if ((rc = ensure(ctx, res.flagged, (size_t)nq * sizeof(int32_t)))) return rc;
         if ((rc = ensure(ctx, res.flag_thr, (size_t)nq * sizeof(float)))) return rc;
@@ -1229,11 +1032,12 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         res.stats[2] = 0;
     }
     if (nshard > 0) {
-        // cell-sort the shards' rows: up to two directions per counting sort (same launches as a grid build)
+        // cell-sort the shards' rows: up to two directions per counting sort (same launches as a grid build); every
+        // shard keeps its own cell starts (the brick kernel finds a brick's queries through them)
         ProfScope ps(ctx, PCCM_K_GRID_BUILD);
-        if ((rc = ensure(ctx, ctx->g_qrecs, (size_t)shard_total * sizeof(GridRec)))) return rc;
-        if ((rc = ensure(ctx, ctx->g_hist, counters_bytes(2 * (gr.ncells + 1))))) return rc;
-        GridRec *qbuf = (GridRec *)ctx->g_qrecs.p;
+        if ((rc = ensure(ctx, ctx->g_qrecs, (size_t)shard_total * rsz))) return rc;
+        if ((rc = ensure(ctx, ctx->g_hist, (size_t)3 * (gr.ncells + 1) * sizeof(uint32_t)))) return rc;
+        char *qbuf = (char *)ctx->g_qrecs.p;
         for (int s0 = 0; s0 < nshard; s0 += 2) {
             const int cnt = nshard - s0 >= 2 ? 2 : 1;
             BuildJobs bj;
@@ -1243,17 +1047,21 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
                 const int dir = shard_dirs[s0 + k];
                 const NNResult &res = ctx->nn[dir];
                 const Cloud &it = ctx->cloud[dir == PCCM_DIR_RIGHT ? 1 : 0];
-                bj.j[k] = {it.xyz64, res.begin, res.end - res.begin, (uint32_t *)ctx->g_hist.p + k * (gr.ncells + 1)};
+                bj.j[k] = {it.xyz64, (const float *)it.xyz32, res.begin, res.end - res.begin,
+                           (uint32_t *)ctx->g_hist.p + (size_t)(s0 + k) * (gr.ncells + 1)};
                 bj.total += res.end - res.begin;
             }
             if (cnt == 1) bj.j[1] = bj.j[0];
             // positions run across the jobs of one sort, i.e. they index qbuf + shard_off[s0]
-            if ((rc = sort_by_cell(ctx, bj, g, (uint32_t *)ctx->g_hist.p, (int64_t)cnt * (gr.ncells + 1), qbuf + shard_off[s0]))) return rc;
+            if ((rc = sort_by_cell(ctx, bj, g, gr.ncells, qbuf + (size_t)shard_off[s0] * rsz, gr.rec32))) return rc;
         }
         for (int s = 0; s < nshard; ++s) {
             const int dir = shard_dirs[s];
             QueryJobs &dst = (dir == PCCM_DIR_SELF) ? selfj : normal;
-            dst.j[job_of_dir[dir]].qrecs = qbuf + shard_off[s];
+            QueryJob &J = dst.j[job_of_dir[dir]];
+            J.qrecs = qbuf + (size_t)shard_off[s] * rsz;
+            J.qbase = qbuf + (size_t)shard_off[s & ~1] * rsz;        // base of the sort this shard took part in
+            J.qcs = (const uint32_t *)ctx->g_hist.p + (size_t)s * (gr.ncells + 1);
         }
     }
     for (int pass = 0; pass < 2; ++pass) {
@@ -1266,28 +1074,28 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
             chunks += jobs.j[k].nchunks;
             nqmax = jobs.j[k].nq > nqmax ? jobs.j[k].nq : nqmax;
         }
-        dim3 tgrid((unsigned)((nqmax + 255) / 256));     // long tails need the whole grid; idle blocks just exit
+        const int64_t qblocks = (nqmax + 255) / 256;
         if (use_coop(ctx)) {
-            dim3 grid((unsigned)((chunks + 3) / 4));
-            const bool shift = jobs.j[0].slack32 != 0.0;       // an input of this pass is not fp32-exact
             {
                 ProfScope ps(ctx, PCCM_K_GRID_QUERY);
-                if (self) {
-                    if (shift) hipLaunchKernelGGL((k_grid_query_coop<true, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                    else hipLaunchKernelGGL((k_grid_query_coop<true, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                if (gr.rec32) {
+                    if ((rc = launch_brick_query(ctx, jobs, g, self))) return rc;
                 } else {
-                    if (shift) hipLaunchKernelGGL((k_grid_query_coop<false, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                    else hipLaunchKernelGGL((k_grid_query_coop<false, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    dim3 grid((unsigned)((chunks + 3) / 4));
+                    if (self) hipLaunchKernelGGL((k_grid_query_coop<true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                    else hipLaunchKernelGGL((k_grid_query_coop<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
                 }
             }
             ProfScope pf(ctx, PCCM_K_GRID_FINISH);
-            if (self) hipLaunchKernelGGL((k_grid_finish<true>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
-            else hipLaunchKernelGGL((k_grid_finish<false>), tgrid, dim3(256), 0, ctx->stream, jobs, g);
+            // tails are short (grid-stride loops inside): a few waves per CU are plenty
+            dim3 tgrid((unsigned)(qblocks < 1024 ? qblocks : 1024));
+            if (gr.rec32) launch_queries<Rec32>(ctx, jobs, g, self, false, tgrid);
+            else launch_queries<GridRec>(ctx, jobs, g, self, false, tgrid);
         } else {
-            dim3 grid((unsigned)((nqmax + 255) / 256));
+            dim3 grid((unsigned)qblocks);
             ProfScope ps(ctx, PCCM_K_GRID_QUERY);
-            if (self) hipLaunchKernelGGL((k_grid_query<true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-            else hipLaunchKernelGGL((k_grid_query<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+            if (gr.rec32) launch_queries<Rec32>(ctx, jobs, g, self, true, grid);
+            else launch_queries<GridRec>(ctx, jobs, g, self, true, grid);
         }
         PCCM_HIP(hipGetLastError());
         {
@@ -1310,7 +1118,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
 void grid_release(pccm_ctx *ctx)
 {
     DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.recs, &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum,
-                      &ctx->g_qrecs};
+                      &ctx->g_qrecs, &ctx->g_bins, &ctx->g_tmp};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
@@ -1321,6 +1129,6 @@ void grid_release(pccm_ctx *ctx)
 
 void grid_invalidate(pccm_ctx *ctx) { ctx->grid.key = 0; }
 
-int grid_ensure(pccm_ctx *ctx) { return ensure_grid(ctx); }
+int grid_ensure(pccm_ctx *ctx, bool need64) { return ensure_grid(ctx, need64); }
 
 }  // namespace pccm

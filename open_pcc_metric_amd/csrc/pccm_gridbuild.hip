@@ -1,0 +1,387 @@
+// Grid build for gfx950: counting sort of both clouds by cell without a single global atomic per point.
+//
+// Stands under the two KDTreeFlann builds of open_pcc_metric/cloud_pair.py:65 (the search structure is
+// rebuilt every step, like the trees).
+//
+// Round 1 ranked every point with one device-scope atomicAdd on its cell counter (78 us for 2M points:
+// scattered agent-scope atomics run ~17x slower than contiguous ones, MI355X_MICROARCH.md "Global float
+// atomics") and scattered 32-byte records from row order.  Here the sort is two-level and every atomic is an
+// LDS atomic:
+//   K_A  k_bin_count    one workgroup per tile of rows: LDS histogram over coarse bins (a bin = a run of
+//                       2^lg consecutive cells), written to hist[job][bin][tile]
+//        k_scan_lookback exclusive scan of hist (bin-major): where each tile's share of each bin starts
+//   K_B  k_bin_scatter  same tiles: LDS cursors seeded from the scan, records go to their bin (tmp array)
+//   K_C  k_bin_sort     one workgroup per bin: cell histogram + ranks by LDS atomics, block scan, cell_start
+//                       written coalesced, records written into their cell (registers hold a bin of up to
+//                       kRegRecs records between the two phases; larger bins are streamed twice)
+// Algorithmic bytes per point (Rec32 records): 12 (K_A) + 12 + 16 (K_B) + 16 + 16 (K_C) = 72, plus
+// 4 B per cell for cell_start.  The order of the records inside a cell depends on the arrival order of
+// LDS atomics; no result depends on it (ties are decided by (d2, row) explicitly).
+#include "pccm_grid.h"
+
+namespace pccm {
+
+// ---- single-pass exclusive scan (decoupled look-back) --------------------------------------------------
+// A tile of 16384 counters per workgroup; tiles are handed out by an atomic ticket, so every predecessor of a
+// running tile is itself running or done and the look-back cannot starve.  Every tile publishes
+// (status, value) in one 64-bit word -- first its own total (status 1), then, once the totals of all earlier
+// tiles are known, its inclusive prefix (status 2); wave 0 of the tile looks back 64 predecessors at a time.
+// `state` = [ntiles] words followed by the ticket counter, all zero on entry.
+constexpr int kLbItems = 64;
+constexpr int kLbTile = 256 * kLbItems;
+
+int64_t scan_tiles(int64_t m) { return (m + kLbTile - 1) / kLbTile; }
+
+__global__ __launch_bounds__(256) void k_scan_lookback(uint32_t *__restrict__ data, int64_t m, unsigned long long *__restrict__ state,
+                                                       int64_t ntiles)
+{
+    __shared__ uint32_t s_tile, s_prefix, wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_tile = (uint32_t)atomicAdd(&state[ntiles], 1ull);
+    __syncthreads();
+    const int64_t tile = s_tile;
+    const int64_t base = tile * kLbTile + (int64_t)tid * kLbItems;
+    uint32_t v[kLbItems], tot = 0;
+    if (base + kLbItems <= m) {
+#pragma unroll
+        for (int k = 0; k < kLbItems; k += 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&data[base + k]);
+            v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kLbItems; ++k) v[k] = (base + k < m) ? data[base + k] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kLbItems; ++k) tot += v[k];
+    uint32_t inc = tot;                                   // inclusive scan of thread totals in the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    const uint32_t agg = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (w == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&state[tile], ((tile == 0 ? 2ull : 1ull) << 32) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        int64_t p = tile - 1;
+        while (p >= 0) {
+            const int64_t idx = p - lane;
+            const unsigned long long st = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                   : (2ull << 32);          // before the first tile: prefix 0
+            const uint32_t status = (uint32_t)(st >> 32), val = (uint32_t)st;
+            const unsigned long long incl = __ballot(status == 2u), empty = __ballot(status == 0u);
+            const int first = incl ? __ffsll((long long)incl) - 1 : 64;     // nearest predecessor with a full prefix
+            const unsigned long long nearer = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
+            if (empty & nearer) {                                            // someone nearer has not published yet
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            uint32_t part = (lane <= first) ? val : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            excl += part;
+            if (first < 64) break;
+            p -= 64;
+        }
+        if (lane == 0) {
+            if (tile > 0) __hip_atomic_store(&state[tile], (2ull << 32) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = excl;
+        }
+    }
+    __syncthreads();
+    uint32_t run = s_prefix + woff + inc - tot;
+    if (base + kLbItems <= m) {
+#pragma unroll
+        for (int k = 0; k < kLbItems; k += 4) {
+            uint4 q;
+            q.x = run; run += v[k];
+            q.y = run; run += v[k + 1];
+            q.z = run; run += v[k + 2];
+            q.w = run; run += v[k + 3];
+            *reinterpret_cast<uint4 *>(&data[base + k]) = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kLbItems; ++k) {
+            if (base + k < m) data[base + k] = run;
+            run += v[k];
+        }
+    }
+}
+
+// ---- the two-level counting sort ---------------------------------------------------------------------------
+constexpr int kRegK = 8;                    // records a thread of k_bin_sort keeps in registers
+constexpr int kRegRecs = 256 * kRegK;
+constexpr int kMaxLg = 13;                  // cells per bin <= 8192 (32 KB of LDS counters)
+
+struct BinJob {
+    const double *x64;
+    const float *x32;
+    int64_t row0, n;
+    uint32_t *cs;          // [ncells + 1]
+    int64_t tl;            // rows per tile
+    int64_t nt;            // tiles of this job
+    int64_t hoff;          // first hist entry of this job (= nbin * tiles of the jobs before it)
+};
+
+struct BinPlan {
+    BinJob j[2];
+    int njobs;
+    int lg;                // log2(cells per bin)
+    int nbin;              // bins per job
+    int64_t ncells;
+    int64_t ntiles;        // all jobs
+    int64_t hlen;          // nbin * ntiles; hist[hlen] is the scan's sentinel (= total after the scan)
+    int64_t state_off;     // uint32 offset of the scan's state words behind the histogram (8-byte aligned)
+    int64_t nstate;        // scan tiles + 1 (the ticket)
+};
+
+template <bool X32>
+__device__ __forceinline__ void load_point(const BinJob &J, int64_t i, double &x, double &y, double &z)
+{
+    const int64_t r = J.row0 + i;
+    if (X32) {
+        const float *q = J.x32 + (r >> 2) * 12 + (r & 3);
+        x = (double)q[0];
+        y = (double)q[4];
+        z = (double)q[8];
+    } else {
+        const double *p = J.x64 + 3 * r;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+    }
+}
+
+// tile -> (job, tile of the job); wave-uniform
+__device__ __forceinline__ int tile_job(const BinPlan &P, int64_t &tile)
+{
+    if (P.njobs > 1 && tile >= P.j[0].nt) {
+        tile -= P.j[0].nt;
+        return 1;
+    }
+    return 0;
+}
+
+template <bool X32>
+__global__ __launch_bounds__(256) void k_bin_count(BinPlan P, GridGeom g, uint32_t *__restrict__ hist)
+{
+    extern __shared__ uint32_t s_hist[];                  // [nbin]
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {                                // the scan's sentinel and state: zero before the scan starts
+        unsigned long long *state = reinterpret_cast<unsigned long long *>(hist + P.state_off);
+        if (tid == 0) hist[P.hlen] = 0u;
+        for (int64_t k = tid; k < P.nstate; k += 256) state[k] = 0ull;
+    }
+    for (int b = tid; b < P.nbin; b += 256) s_hist[b] = 0u;
+    __syncthreads();
+    int64_t tile = blockIdx.x;
+    const int jb = tile_job(P, tile);
+    const BinJob &J = P.j[jb];
+    const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
+    for (int64_t i = i0 + tid; i < i1; i += 1024) {       // four independent rows per trip
+        uint32_t bin[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t ii = i + 256 * k;
+            double x, y, z;
+            load_point<X32>(J, ii < i1 ? ii : i1 - 1, x, y, z);
+            bin[k] = cell_linear(g, x, y, z) >> P.lg;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + 256 * k < i1) atomicAdd(&s_hist[bin[k]], 1u);
+    }
+    __syncthreads();
+    uint32_t *dst = hist + J.hoff + tile;
+    for (int b = tid; b < P.nbin; b += 256) dst[(int64_t)b * J.nt] = s_hist[b];
+}
+
+template <typename REC, bool X32>
+__global__ __launch_bounds__(256) void k_bin_scatter(BinPlan P, GridGeom g, const uint32_t *__restrict__ hist, REC *__restrict__ tmp)
+{
+    extern __shared__ uint32_t s_cur[];                   // [nbin]: next free position of each bin's share of this tile
+    const int tid = threadIdx.x;
+    int64_t tile = blockIdx.x;
+    const int jb = tile_job(P, tile);
+    const BinJob &J = P.j[jb];
+    const uint32_t *src = hist + J.hoff + tile;
+    for (int b = tid; b < P.nbin; b += 256) s_cur[b] = src[(int64_t)b * J.nt];
+    __syncthreads();
+    const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
+    for (int64_t i = i0 + tid; i < i1; i += 1024) {
+        P3 v[4];
+        uint32_t bin[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t ii = (i + 256 * k < i1) ? i + 256 * k : i1 - 1;
+            load_point<X32>(J, ii, v[k].x, v[k].y, v[k].z);
+            v[k].row = (int)(J.row0 + ii);
+            bin[k] = cell_linear(g, v[k].x, v[k].y, v[k].z) >> P.lg;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + 256 * k < i1) {
+                const uint32_t pos = atomicAdd(&s_cur[bin[k]], 1u);
+                store_rec(tmp, pos, v[k]);
+            }
+    }
+}
+
+// block-wide exclusive scan of s_cnt[0..nc) in place (256 threads); returns nothing, leaves offsets
+__device__ __forceinline__ void block_scan_inplace(uint32_t *s_cnt, int nc, uint32_t *s_wsum, uint32_t *s_carry)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) *s_carry = 0u;
+    __syncthreads();
+    for (int base = 0; base < nc; base += 1024) {
+        // four consecutive counters per thread: one 16-byte LDS access each way
+        const int e = base + 4 * tid;
+        uint32_t c0 = e < nc ? s_cnt[e] : 0u, c1 = e + 1 < nc ? s_cnt[e + 1] : 0u;
+        uint32_t c2 = e + 2 < nc ? s_cnt[e + 2] : 0u, c3 = e + 3 < nc ? s_cnt[e + 3] : 0u;
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wsum[w] = inc;
+        __syncthreads();
+        uint32_t run = *s_carry + inc - tot;
+        for (int k = 0; k < w; ++k) run += s_wsum[k];
+        if (e < nc) s_cnt[e] = run;
+        run += c0;
+        if (e + 1 < nc) s_cnt[e + 1] = run;
+        run += c1;
+        if (e + 2 < nc) s_cnt[e + 2] = run;
+        run += c2;
+        if (e + 3 < nc) s_cnt[e + 3] = run;
+        __syncthreads();
+        if (tid == 255) *s_carry = run + c3;
+        __syncthreads();
+    }
+}
+
+template <typename REC>
+__global__ __launch_bounds__(256) void k_bin_sort(BinPlan P, GridGeom g, const uint32_t *__restrict__ hist, const REC *__restrict__ tmp,
+                                                  REC *__restrict__ recs)
+{
+    extern __shared__ uint32_t s_cnt[];                   // [cells of a bin]
+    __shared__ uint32_t s_wsum[4], s_carry;
+    const int tid = threadIdx.x;
+    const int jb = (P.njobs > 1 && (int)blockIdx.x >= P.nbin) ? 1 : 0;
+    const int b = (int)blockIdx.x - jb * P.nbin;
+    const BinJob &J = P.j[jb];
+    const uint32_t s = hist[J.hoff + (int64_t)b * J.nt], e = hist[J.hoff + (int64_t)(b + 1) * J.nt];
+    const uint32_t m = e - s;
+    const int64_t c0 = (int64_t)b << P.lg;
+    const int nc = (int)((c0 + (1ll << P.lg) < P.ncells ? c0 + (1ll << P.lg) : P.ncells) - c0);
+    for (int c = tid; c < nc; c += 256) s_cnt[c] = 0u;
+    __syncthreads();
+    if (m <= (uint32_t)kRegRecs) {
+        // the whole bin in registers: rank by the counting atomic, place after the scan
+        P3 v[kRegK];
+        uint32_t cell[kRegK], rank[kRegK];
+#pragma unroll
+        for (int k = 0; k < kRegK; ++k) {
+            const uint32_t i = tid + 256u * k;
+            if (i < m) {
+                v[k] = load_rec(tmp, s + i);
+                cell[k] = cell_linear(g, v[k].x, v[k].y, v[k].z) - (uint32_t)c0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRegK; ++k)
+            if (tid + 256u * k < m) rank[k] = atomicAdd(&s_cnt[cell[k]], 1u);
+        __syncthreads();
+        block_scan_inplace(s_cnt, nc, s_wsum, &s_carry);
+        for (int c = tid; c < nc; c += 256) J.cs[c0 + c] = s + s_cnt[c];
+#pragma unroll
+        for (int k = 0; k < kRegK; ++k)
+            if (tid + 256u * k < m) store_rec(recs, s + s_cnt[cell[k]] + rank[k], v[k]);
+    } else {
+        for (uint32_t i = tid; i < m; i += 256) {
+            const P3 v = load_rec(tmp, s + i);
+            atomicAdd(&s_cnt[cell_linear(g, v.x, v.y, v.z) - (uint32_t)c0], 1u);
+        }
+        __syncthreads();
+        block_scan_inplace(s_cnt, nc, s_wsum, &s_carry);
+        for (int c = tid; c < nc; c += 256) J.cs[c0 + c] = s + s_cnt[c];
+        __syncthreads();                                   // cell_start is out: the offsets become cursors
+        for (uint32_t i = tid; i < m; i += 256) {
+            const P3 v = load_rec(tmp, s + i);
+            const uint32_t pos = atomicAdd(&s_cnt[cell_linear(g, v.x, v.y, v.z) - (uint32_t)c0], 1u);
+            store_rec(recs, s + pos, v);
+        }
+    }
+    if (b == P.nbin - 1 && tid == 0) J.cs[P.ncells] = e;  // end of the job's records
+}
+
+static int ceil_log2(int64_t v)
+{
+    int l = 0;
+    while ((1ll << l) < v) ++l;
+    return l;
+}
+
+int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_t ncells, void *recs, bool rec32)
+{
+    BinPlan P;
+    P.njobs = jobs.njobs;
+    P.ncells = ncells;
+    int lg = ceil_log2((ncells + 4095) / 4096);
+    P.lg = lg < 10 ? 10 : (lg > kMaxLg ? kMaxLg : lg);
+    P.nbin = (int)((ncells + (1ll << P.lg) - 1) >> P.lg);
+    if (P.nbin > 8192) return fail(PCCM_E_ARG, "grid of %lld cells is too large", (long long)ncells);
+    P.ntiles = 0;
+    for (int k = 0; k < 2; ++k) {
+        const BuildJob &s = jobs.j[k < jobs.njobs ? k : 0];
+        BinJob &d = P.j[k];
+        d.x64 = s.x64; d.x32 = s.x32; d.row0 = s.row0; d.cs = s.cs;
+        d.n = k < jobs.njobs ? s.n : 0;
+        int64_t nt = (d.n + 2047) / 2048;
+        if (nt > 1024) nt = 1024;
+        d.nt = nt;
+        d.tl = nt > 0 ? ((d.n + nt - 1) / nt + 255) / 256 * 256 : 256;
+        if (nt > 0) d.nt = (d.n + d.tl - 1) / d.tl;       // rounding tl up may leave the last tiles empty: drop them
+        d.hoff = (int64_t)P.nbin * P.ntiles;
+        if (k < jobs.njobs) P.ntiles += d.nt;
+    }
+    P.hlen = (int64_t)P.nbin * P.ntiles;
+    const int64_t st = scan_tiles(P.hlen + 1);
+    P.nstate = st + 1;
+    P.state_off = (P.hlen + 2) / 2 * 2;
+    const size_t rsz = rec32 ? sizeof(Rec32) : sizeof(GridRec);
+    const size_t hist_bytes = (size_t)P.state_off * sizeof(uint32_t) + (size_t)P.nstate * 8;
+    int rc;
+    if ((rc = ensure(ctx, ctx->g_bins, hist_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->g_tmp, (size_t)(jobs.total > 0 ? jobs.total : 1) * rsz))) return rc;
+    uint32_t *hist = (uint32_t *)ctx->g_bins.p;
+    unsigned long long *state = reinterpret_cast<unsigned long long *>(hist + P.state_off);
+    const size_t lds_bins = (size_t)P.nbin * sizeof(uint32_t), lds_cells = ((size_t)1 << P.lg) * sizeof(uint32_t);
+    if (P.ntiles > 0) {
+        dim3 tg((unsigned)P.ntiles);
+        if (rec32) hipLaunchKernelGGL((k_bin_count<true>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
+        else hipLaunchKernelGGL((k_bin_count<false>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
+        hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)st), dim3(256), 0, ctx->stream, hist, P.hlen + 1, state, st);
+        if (rec32) hipLaunchKernelGGL((k_bin_scatter<Rec32, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (Rec32 *)ctx->g_tmp.p);
+        else hipLaunchKernelGGL((k_bin_scatter<GridRec, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (GridRec *)ctx->g_tmp.p);
+    } else {
+        PCCM_HIP(hipMemsetAsync(hist, 0, hist_bytes, ctx->stream));
+    }
+    dim3 bg((unsigned)(P.nbin * P.njobs));
+    if (rec32) hipLaunchKernelGGL((k_bin_sort<Rec32>), bg, dim3(256), lds_cells, ctx->stream, P, g, (const uint32_t *)hist, (const Rec32 *)ctx->g_tmp.p, (Rec32 *)recs);
+    else hipLaunchKernelGGL((k_bin_sort<GridRec>), bg, dim3(256), lds_cells, ctx->stream, P, g, (const uint32_t *)hist, (const GridRec *)ctx->g_tmp.p, (GridRec *)recs);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+}  // namespace pccm

@@ -50,9 +50,13 @@ struct DevBuf {
 struct NNResult {
     bool valid = false;
     int64_t begin = 0, end = 0; // shard rows of the iterating cloud
-    int32_t *idx = nullptr;     // [end-begin]
-    double *d2 = nullptr;       // [end-begin]
+    int32_t *idx = nullptr;     // [end-begin]   plain columns: written by the brute-force engine, or unpacked from `rec`
+    double *d2 = nullptr;       // [end-begin]   on demand (ensure_plain)
     int64_t cap = 0;
+    DevBuf rec;                 // [end-begin] 32-byte result records {d2, projection, row, -} (grid engine; NNOut in pccm_grid.h)
+    bool rec_valid = false;     // `rec` holds the last run's results
+    bool plain_valid = false;   // idx / d2 hold them
+    int fused_mode = -1;        // normal mode of the projection stored in `rec`, -1: not fused
     int64_t stats[3] = {0, 0, 0};
     uint32_t *nflag_dev = nullptr;  // device counters of the last run: [0] fallback queries, [1] grid tail length
     DevBuf flagged, flag_thr;       // queries handed to the exact rescan (k2b_fallback) and their thresholds
@@ -97,12 +101,13 @@ struct Grid {                    // one geometry, both clouds (grid engine)
     PairSignature sig;             // of the pair the decisions were last taken (or inherited) for
     uint64_t iso_key = 0;          // pair the isolation count below was taken for
     int64_t isolated[2] = {0, 0};  // points of cloud k with nothing of the other cloud within kMaxRing cells
+    bool rec32 = false;            // records are Rec32 (both clouds fp32-exact) instead of GridRec
     int dim[3] = {1, 1, 1};
     double org[3] = {0, 0, 0};
     double h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};   // cell edge per axis
     int64_t ncells = 0, n[2] = {0, 0};
     DevBuf cell_start;             // uint32 [2][ncells + 1]: positions in recs
-    DevBuf recs;                   // GridRec [n[0] + n[1]]: cloud 0's records, then cloud 1's
+    DevBuf recs;                   // GridRec or Rec32 [n[0] + n[1]]: cloud 0's records, then cloud 1's
 };
 
 struct ReduceSlot {            // one enqueued reduction (pccm_reduce_prefetch / pccm_reduce)
@@ -125,6 +130,8 @@ struct ProfSpan {
 struct GraphOp {               // host-side effect of one captured call, replayed by pccm_graph_launch
     int kind = 0;              // 0 drop_caches, 1 nn(dir), 2 reduce_prefetch(slot)
     int dir = 0, slot = -1;
+    bool rec_valid = false, plain_valid = false;   // kind 1: where the direction's results live once the graph has run
+    int fused_mode = -1;
     ReduceSlot snap;           // kind 2: the slot's bookkeeping at capture time (pointers are not owned)
 };
 
@@ -154,6 +161,9 @@ struct pccm_ctx {
     pccm::DevBuf color_cols, color_idx;   // colour pass: squares as three columns / caller-supplied neighbour rows
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
+    pccm::DevBuf g_bins, g_tmp;            // grid build: per-tile bin histogram + scan state; bin-partitioned records
+    bool colsum_configured = false;        // k_color_colsum's dynamic-LDS opt-in was set on this context's device
+    int fuse_mode[3] = {-1, -1, -1};       // pccm_nn_fuse: normal mode of the D2 projection fused into the search, per direction
     pccm::ReduceSlot slots[8];
     uint64_t nn_gen[3] = {1, 1, 1};
     // hipGraph capture of a step (pccm_graph_*): epoch changes whenever inputs, shard or any device
@@ -205,7 +215,7 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
 int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs);
 void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
-int grid_ensure(pccm_ctx *ctx);
+int grid_ensure(pccm_ctx *ctx, bool need64 = false);   // need64: GridRec records wanted (pccm_normals.hip reads them)
 int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the current pair (cached per pair)
 int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)
 int estimate_normals(pccm_ctx *ctx, int which, int k);
@@ -220,8 +230,11 @@ struct RescanJob {              // flagged queries of one result (k2b_fallback)
     const int32_t *flagged;     // rows relative to q_begin
     const float *flag_thr;      // fp32 filter threshold of each
     const uint32_t *nflag;      // list length (device)
-    int32_t *idx_out;
+    int32_t *idx_out;           // plain outputs (brute-force engine) ...
     double *d2_out;
+    double4 *rec_out;           // ... or 32-byte result records with the projection fused (grid engine), when non-null
+    const double *nrm;          // normals for the fused projection, or null
+    int normal_mode;
     double *part_d;             // split regime: [kSplitMax][gridDim.x] partial minima
     int32_t *part_j;
     uint32_t *ticket;           // split regime: workgroups done (self-resetting)
@@ -244,7 +257,9 @@ struct PointJobs {
     int64_t off[5];             // prefix sums of the jobs' row counts
 };
 struct UnitJob {                // one column to reduce (k_unit_jobs)
-    const double *val;
+    const double *val;          // element i at val[i * stride]
+    int stride;                 // in doubles: 1 = plain column, 4 = a field of the 32-byte result records
+    int square;                 // reduce val^2 (the D2 column from the records' signed projection; metric.py:179)
     int64_t ns, nunits;
     int64_t tail_first, tail_n; // rows [tail_first, tail_first + tail_n) are copied out raw
     int64_t nblocks;            // ceil(nunits / 32)
@@ -259,6 +274,7 @@ struct UnitJobs {
     int64_t toff[9];            // prefix sums of tail_n
 };
 int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs);
+int launch_unpack(pccm_ctx *ctx, const double4 *rec, int64_t ns, int32_t *idx, double *d2);   // result records -> plain columns
 int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs);
 
 int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,

@@ -417,7 +417,7 @@ int estimate_normals(pccm_ctx *ctx, int which, int k)
     if (c.n <= 0) return fail(PCCM_E_STATE, "cloud %d is not set", which);
     if (k < 3 || k > kKnnMax) return fail(PCCM_E_ARG, "k must be in 3..%d", kKnnMax);
     int rc;
-    if ((rc = grid_ensure(ctx))) return rc;
+    if ((rc = grid_ensure(ctx, true))) return rc;      // this file reads GridRec (fp64) records
     const Grid &gr = ctx->grid;
     KnnGeom g;
     for (int a = 0; a < 3; ++a) {

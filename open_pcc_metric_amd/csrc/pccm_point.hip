@@ -246,23 +246,32 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
         const int64_t u = (t - jobs.uoff[jb]) >> 3;
         const int k = threadIdx.x & 7, grp = threadIdx.x >> 3;
         const double *__restrict__ val = J.val;
+        const int64_t st = J.stride;
+        const bool sq = J.square != 0;
         const int64_t base = u * kLeaf;
         const bool live = u < J.nunits;
         const int64_t cnt = !live ? 0 : ((J.ns - base < kLeaf) ? J.ns - base : kLeaf);
         double r = 0.0, mn = INFINITY, mx = -INFINITY;
         if (cnt == kLeaf) {
-            r = val[base + k];
+            double v[kLeaf / 8];
+#pragma unroll
+            for (int j = 0; j < kLeaf / 8; ++j) v[j] = val[(base + 8 * j + k) * st];      // independent loads first
+            if (sq) {
+#pragma unroll
+                for (int j = 0; j < kLeaf / 8; ++j) v[j] = __dmul_rn(v[j], v[j]);
+            }
+            r = v[0];
             mn = mx = r;
 #pragma unroll
             for (int j = 1; j < kLeaf / 8; ++j) {
-                double v = val[base + 8 * j + k];
-                r = __dadd_rn(r, v);
-                mn = fmin(mn, v);
-                mx = fmax(mx, v);
+                r = __dadd_rn(r, v[j]);
+                mn = fmin(mn, v[j]);
+                mx = fmax(mx, v[j]);
             }
         } else {
             for (int64_t e = k; e < cnt; e += 8) {
-                double v = val[base + e];
+                double v = val[(base + e) * st];
+                if (sq) v = __dmul_rn(v, v);
                 r = __dadd_rn(r, v);
                 mn = fmin(mn, v);
                 mx = fmax(mx, v);
@@ -314,7 +323,8 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
         if (k < jobs.njobs && c >= jobs.toff[k]) jb = k;
     const UnitJob &J = jobs.j[jb];
     const int64_t e = c - jobs.toff[jb];
-    J.out_tail[e] = J.val[J.tail_first + e];
+    const double v = J.val[(J.tail_first + e) * J.stride];
+    J.out_tail[e] = J.square ? __dmul_rn(v, v) : v;
 }
 
 int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
@@ -323,6 +333,25 @@ int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
     if (total <= 0) return PCCM_OK;
     ProfScope ps(ctx, PCCM_K_REDUCE);
     hipLaunchKernelGGL(k_unit_jobs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, jobs);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+// Result records -> plain columns (only when a consumer wants them: colour kernels, getters, pccm_nn_fetch).
+__global__ __launch_bounds__(256) void k_unpack(const double4 *__restrict__ rec, int64_t ns, int32_t *__restrict__ idx,
+                                                double *__restrict__ d2)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const double4 r = rec[i];
+    idx[i] = (int32_t)(__double_as_longlong(r.z) & 0xffffffffll);
+    d2[i] = r.x;
+}
+
+int launch_unpack(pccm_ctx *ctx, const double4 *rec, int64_t ns, int32_t *idx, double *d2)
+{
+    if (ns <= 0) return PCCM_OK;
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rec, ns, idx, d2);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }

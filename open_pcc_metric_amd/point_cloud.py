@@ -45,6 +45,10 @@ class PointCloud:
         if u8.shape != self._colors.shape:
             raise ValueError("colors_u8 must match colors")
         self.colors_u8 = u8
+        # the two views must not drift apart: with the bytes attached, colors can only change through the setter
+        # (which drops the bytes); an in-place edit raises instead of leaving stale bytes for the GPU
+        if isinstance(self._colors, np.ndarray):
+            self._colors.setflags(write=False)
 
     def has_points(self) -> bool:
         return len(self._points) > 0

@@ -138,7 +138,8 @@ class OracleEngine:
         if nrm is None:
             raise RuntimeError("no normals")
         if normal_mode == "row":
-            if e > nrm.shape[0]:
+            # as libpccm's check_normals: sharded, the WHOLE iterating cloud decides, so that every rank raises
+            if (self.n_iter(d) if self.world > 1 else e) > nrm.shape[0]:
                 raise IndexError(f"index {nrm.shape[0]} is out of bounds for axis 0 with size {nrm.shape[0]}")
             rows = nrm[b:e]
             proj = orc.point_to_plane(self.pts[it][b:e], self.pts[se], idx, np.ascontiguousarray(rows))

@@ -82,3 +82,53 @@ def test_two_gloo_ranks_match_single_process(tmp_path, n):
     assert outs[0]["col_len"] == n + 37
     assert outs[0]["col_sum"] == float(np.sum(np.asarray(pair.get_right_neighbour_distances()))).hex()
     assert outs[0]["ev_sum"] == float(np.sum(np.asarray(pair.get_left_error_vector()))).hex()
+
+
+Q1_WORKER = r'''
+import json, os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["PCCM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PCCM_ROOT"], "tests"))
+from open_pcc_metric_amd.calculator import MetricCalculator
+from open_pcc_metric_amd.cloud_pair import CloudPair
+from open_pcc_metric_amd.options import CalculateOptions, transform_options
+from open_pcc_metric_amd.point_cloud import PointCloud
+from oracle_engine import OracleEngine
+
+dist.init_process_group("gloo")
+n = int(os.environ["PCCM_N"])
+rng = np.random.default_rng(7)
+a = rng.random((n + 300, 3), dtype=np.float32); b = rng.random((n, 3), dtype=np.float32)     # A larger than B
+na = rng.standard_normal((n + 300, 3)); nb = rng.standard_normal((n, 3))
+pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], group=dist.group.WORLD, _engine=OracleEngine())
+outcome = "no error"
+try:
+    MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, False, True)))   # default normal_index="row"
+except IndexError as exc:
+    outcome = "IndexError: " + str(exc)
+with open(os.path.join(os.environ["PCCM_OUT"], f"q1_rank{dist.get_rank()}.json"), "w") as fh:
+    json.dump({"rank": dist.get_rank(), "outcome": outcome, "shard": pair._engine.shard_range(0)}, fh)
+dist.destroy_process_group()
+'''
+
+
+def test_row_indexed_normals_out_of_range_raise_on_every_rank(tmp_path):
+    """Reference quirk Q1 (metric.py:148-152: normals_other[i] with i up to len(iterating cloud)) under sharding:
+    only the LAST rank's shard reaches past the other cloud's normals, yet every rank must raise the reference's
+    IndexError -- a per-shard decision would leave the low ranks waiting in the all-reduce (ADVICE r1, medium)."""
+    n = 3000
+    script = tmp_path / "q1_worker.py"
+    script.write_text(Q1_WORKER)
+    env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1", PCCM_OUT=str(tmp_path))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)       # a hang would trip the timeout
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    outs = [json.load(open(tmp_path / f"q1_rank{r}.json")) for r in (0, 1)]
+    assert outs[0]["shard"][1] <= n < outs[1]["shard"][1]          # rank 0's own rows are all in range, rank 1's are not
+    for o in outs:
+        assert o["outcome"].startswith("IndexError"), o
