@@ -116,6 +116,12 @@ int pccm_get_normals(pccm_ctx *ctx, int which, double *out);
  * [begin, end) of the iterating cloud returned by pccm_shard_range (boundaries are multiples
  * of 128 rows so that reduction leaves never straddle ranks).  Default: rank 0 of 1. */
 int pccm_set_shard(pccm_ctx *ctx, int rank, int world);
+/* The same per direction: `world` ranks share the rows of direction `dir` and this context is number `rank` of them;
+ * world = 0: this context owns NO rows of that direction (another group of ranks searches it) -- its searches and
+ * reductions of `dir` are empty and contribute zeros to the exchange.  Lets the ranks of a node split by DIRECTION
+ * first (cloud_pair.py:67-72 on one half, :73-78 on the other), so that every rank builds the search structure of one
+ * cloud only. */
+int pccm_set_shard_dir(pccm_ctx *ctx, int dir, int rank, int world);
 int pccm_shard_range(pccm_ctx *ctx, int dir, int64_t *begin, int64_t *end);
 
 /* Replaces get_neighbour_cloud(), cloud_pair.py:10-42 (and, for PCCM_DIR_SELF, Open3D's

@@ -29,7 +29,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
-    "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_fetch",
+    "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
     "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
@@ -87,6 +87,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_set_cloud.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_set_normals.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_set_shard.argtypes = [vp, i32, i32]
+    lib.pccm_set_shard_dir.argtypes = [vp, i32, i32, i32]
     lib.pccm_estimate_normals.argtypes = [vp, i32, i32]
     lib.pccm_get_normals.argtypes = [vp, i32, vp]
     lib.pccm_shard_range.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
@@ -382,6 +383,11 @@ class Engine:
 
     def set_shard(self, rank: int, world: int) -> None:
         _check(self._lib.pccm_set_shard(self._ctx, int(rank), int(world)))
+
+    def set_shard_dir(self, direction: int, rank: int, world: int) -> None:
+        """This context is number ``rank`` of the ``world`` ranks that share the rows of ``direction``; world 0: it
+        owns none of them (pccm_set_shard_dir)."""
+        _check(self._lib.pccm_set_shard_dir(self._ctx, int(direction), int(rank), int(world)))
 
     def shard_range(self, direction: int) -> Tuple[int, int]:
         b, e = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -20,7 +20,9 @@ Differences from the reference, all deliberate:
   matched point's normal;
 * exact ties go to the smallest row index (Open3D's order is traversal dependent);
 * ``extent=`` injects ``get_extent()`` (the minimal-OBB is CPU code and not parity-pinned);
-* ``group=`` shards the query axis over the ranks of a ``torch.distributed`` group;
+* ``group=`` shards the pair over the ranks of a ``torch.distributed`` group: by direction first (half of the ranks
+  search cloud_pair.py:67-72, the other half :73-78, so every rank builds one cloud's search structure), then by
+  query rows inside each half (``shard_mode="rows"``: every rank takes rows of both directions, as in round 1);
 * ``use_graph=True`` lets ``recompute()`` replay the whole sweep + reductions of the previous report
   as one hipGraph launch (for callers that evaluate the same resident pair repeatedly).
 """
@@ -240,7 +242,8 @@ class CloudPair:
 
     def __init__(self, origin_cloud, reconst_cloud, *, device: typing.Optional[int] = None,
                  nn_engine: str = "auto", normal_index: str = "row", extent=None, group=None,
-                 use_graph: bool = False, estimate_normals: bool = True, normals_knn: int = 30, _engine=None):
+                 use_graph: bool = False, estimate_normals: bool = True, normals_knn: int = 30,
+                 shard_mode: str = "direction", _engine=None):
         if normal_index not in nat.NORMAL_MODES:
             raise ValueError("normal_index must be 'row' or 'neighbour'")
         if nn_engine not in nat.ENGINES:
@@ -270,8 +273,15 @@ class CloudPair:
             _engine.set_cloud(k, cloud.points)
             if _has_normals(cloud):
                 _engine.set_normals(k, cloud.normals)
+        if shard_mode not in ("direction", "rows"):
+            raise ValueError("shard_mode must be 'direction' or 'rows'")
+        self._plan = shard_plan(self._coll.world, shard_mode if hasattr(_engine, "set_shard_dir") else "rows")
         if self._coll.sharded:
-            _engine.set_shard(self._coll.rank, self._coll.world)
+            if hasattr(_engine, "set_shard_dir"):
+                for direction in (nat.DIR_LEFT, nat.DIR_RIGHT, nat.DIR_SELF):
+                    _engine.set_shard_dir(direction, *self._plan[direction][self._coll.rank])
+            else:
+                _engine.set_shard(self._coll.rank, self._coll.world)
         self._update_fusion()
         self.recompute()
 
@@ -355,7 +365,7 @@ class CloudPair:
         if not self._coll.sharded:
             return local
         n = self._engine.n_iter(direction)
-        counts = [_shard_bounds(n, r, self._coll.world) for r in range(self._coll.world)]
+        counts = [_shard_bounds(n, *self._plan[direction][r]) for r in range(self._coll.world)]
         return self._coll.allgather_rows(local, [e - b for b, e in counts])
 
     def _sharded_reduction(self, direction: int, metric: int):
@@ -562,7 +572,28 @@ def _host_rows(a) -> np.ndarray:
     return np.asarray(a)
 
 
+def shard_plan(world: int, mode: str = "direction"):
+    """Who searches what: ``plan[direction][rank] = (sub_rank, sub_world)`` -- rank ``rank`` is number ``sub_rank`` of the
+    ``sub_world`` ranks that share the rows of ``direction`` (sub_world 0: it owns none of them).
+
+    "direction" (default, world >= 2): the first half of the ranks takes the left direction (A's rows searched in B:
+    they build B's grid only), the second half the right direction and the self search of A (both search A).  The
+    replicated part of a step -- the search-structure build -- is halved that way and each half shards its rows; the
+    all-gathers of materialised columns concatenate ranks in rank order, which is row order inside each half.
+    "rows": every rank takes the same row range of every direction (round 1)."""
+    if world <= 1 or mode == "rows":
+        same = [(r, world) for r in range(world)]
+        return {nat.DIR_LEFT: same, nat.DIR_RIGHT: list(same), nat.DIR_SELF: list(same)}
+    nl = (world + 1) // 2
+    nr = world - nl
+    left = [(r, nl) if r < nl else (0, 0) for r in range(world)]
+    right = [(r - nl, nr) if r >= nl else (0, 0) for r in range(world)]
+    return {nat.DIR_LEFT: left, nat.DIR_RIGHT: right, nat.DIR_SELF: list(right)}
+
+
 def _shard_bounds(n: int, rank: int, world: int):
-    """Rows of an n-row cloud owned by ``rank``: the rule of pccm_set_shard (128-row units)."""
+    """Rows of an n-row cloud owned by ``rank``: the rule of pccm_set_shard (128-row units); world 0 owns nothing."""
+    if world <= 0:
+        return 0, 0
     units = (n + 127) // 128
     return min(n, units * rank // world * 128), min(n, units * (rank + 1) // world * 128)

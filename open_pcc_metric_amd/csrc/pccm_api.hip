@@ -142,6 +142,11 @@ static void free_nn(NNResult &r)
 
 static void shard_of(int64_t n, int rank, int world, int64_t *b, int64_t *e)
 {
+    if (world <= 0) {                     // this context owns no rows of the direction
+        *b = 0;
+        *e = 0;
+        return;
+    }
     const int64_t units = (n + kLeaf - 1) / kLeaf;
     int64_t u0 = units * rank / world, u1 = units * (rank + 1) / world;
     int64_t lo = u0 * kLeaf, hi = u1 * kLeaf;
@@ -613,10 +618,26 @@ int pccm_set_shard(pccm_ctx *ctx, int rank, int world)
     CHECK_CTX(ctx);
     NOT_CAPTURING(ctx);
     if (world < 1 || rank < 0 || rank >= world) return fail(PCCM_E_ARG, "bad shard %d of %d", rank, world);
-    ctx->rank = rank;
-    ctx->world = world;
+    for (int d = 0; d < 3; ++d) {
+        ctx->shard_rank[d] = rank;
+        ctx->shard_world[d] = world;
+    }
     ctx->epoch++;
     for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
+    return PCCM_OK;
+}
+
+int pccm_set_shard_dir(pccm_ctx *ctx, int dir, int rank, int world)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
+    if (world < 0 || (world > 0 && (rank < 0 || rank >= world))) return fail(PCCM_E_ARG, "bad shard %d of %d", rank, world);
+    ctx->shard_rank[dir] = world > 0 ? rank : 0;
+    ctx->shard_world[dir] = world;
+    ctx->epoch++;
+    ctx->nn[dir].valid = false;
+    ctx->nn_gen[dir]++;
     return PCCM_OK;
 }
 
@@ -627,7 +648,7 @@ int pccm_shard_range(pccm_ctx *ctx, int dir, int64_t *begin, int64_t *end)
     const Cloud *it, *se;
     int rc = dir_clouds(ctx, dir, &it, &se);
     if (rc) return rc;
-    shard_of(it->n, ctx->rank, ctx->world, begin, end);
+    shard_of(it->n, ctx->shard_rank[dir], ctx->shard_world[dir], begin, end);
     return PCCM_OK;
 }
 
@@ -640,7 +661,7 @@ static int prepare_nn(pccm_ctx *ctx, int dir, int *trivial)
     NNResult &res = ctx->nn[dir];
     res.valid = false;
     ctx->nn_gen[dir]++;
-    shard_of(it->n, ctx->rank, ctx->world, &res.begin, &res.end);
+    shard_of(it->n, ctx->shard_rank[dir], ctx->shard_world[dir], &res.begin, &res.end);
     const int64_t ns = res.end - res.begin;
     if (ctx->capturing) {
         GraphOp op;
@@ -799,7 +820,7 @@ static int check_normals(const pccm_ctx *ctx, const Cloud &it, const Cloud &se, 
     if (se.n_nrm <= 0) return fail(PCCM_E_STATE, "the searched cloud has no normals (pccm_set_normals)");
     // sharded: the test is on the whole iterating cloud, so that every rank raises (or none does) -- a per-shard test
     // would let the low ranks walk into the exchange while the last one raises
-    if (normal_mode == PCCM_NORMAL_ROW && (ctx->world > 1 ? it.n : res.end) > se.n_nrm)
+    if (normal_mode == PCCM_NORMAL_ROW && (ctx->sharded() ? it.n : res.end) > se.n_nrm)
         return fail(PCCM_E_RANGE, "index %lld is out of bounds for axis 0 with size %lld (row-indexed normals, reference quirk Q1)",
                     (long long)se.n_nrm, (long long)se.n_nrm);
     if (normal_mode == PCCM_NORMAL_NEIGHBOUR && se.n_nrm != se.n)
@@ -946,17 +967,35 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     }
     if (!s.ev) PCCM_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
     if (s.nunits > 0) {
-        UnitJob &U = uj.j[uj.njobs];
-        U.val = dev; U.stride = stride; U.square = square; U.ns = ns; U.nunits = s.nunits;
-        U.tail_first = s.t0 - res->begin; U.tail_n = s.tail_n;
-        U.nblocks = s.nblocks;
-        U.out_units = want_units ? s.host : nullptr;
-        U.out_blocks = s.host + 3 * s.nunits;
-        U.out_tail = s.host + 3 * s.nunits + 3 * s.nblocks;
-        const int64_t lanes = (s.nunits * 8 + 255) / 256 * 256;
-        uj.uoff[uj.njobs + 1] = uj.uoff[uj.njobs] + lanes;
-        uj.toff[uj.njobs + 1] = uj.toff[uj.njobs] + s.tail_n;
-        uj.njobs++;
+        UnitCol col;
+        col.off = (stride == 4 && metric != PCCM_METRIC_D1) ? 1 : 0;
+        col.square = square;
+        col.out_units = want_units ? s.host : nullptr;
+        col.out_blocks = s.host + 3 * s.nunits;
+        col.out_tail = s.host + 3 * s.nunits + 3 * s.nblocks;
+        // a second column over the same result records rides along with the job that already reads them
+        const double *base = stride == 4 ? (const double *)res->rec.p : dev;
+        UnitJob *host_job = nullptr;
+        static const bool merge = [] { const char *e = getenv("PCCM_REDUCE_MERGE"); return !(e && e[0] == '0'); }();
+        if (stride == 4 && merge)
+            for (int k = 0; k < uj.njobs; ++k)
+                if (uj.j[k].stride == 4 && uj.j[k].val == base && uj.j[k].ncols == 1) host_job = &uj.j[k];
+        if (host_job) {
+            host_job->c[1] = col;
+            host_job->ncols = 2;
+        } else {
+            if (uj.njobs >= 8) return fail(PCCM_E_ARG, "too many columns in one reduction batch");
+            UnitJob &U = uj.j[uj.njobs];
+            U.val = base; U.stride = stride; U.ncols = 1;
+            U.c[0] = col; U.c[1] = col;
+            U.ns = ns; U.nunits = s.nunits;
+            U.tail_first = s.t0 - res->begin; U.tail_n = s.tail_n;
+            U.nblocks = s.nblocks;
+            const int64_t lanes = (s.nunits * 8 + 255) / 256 * 256;
+            uj.uoff[uj.njobs + 1] = uj.uoff[uj.njobs] + lanes;
+            uj.toff[uj.njobs + 1] = uj.toff[uj.njobs] + s.tail_n;
+            uj.njobs++;
+        }
     }
     return PCCM_OK;
 }
@@ -983,7 +1022,7 @@ int pccm_reduce_prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *
 {
     CHECK_CTX(ctx);
     // per-leaf results cross PCIe only when a sharded exchange will need them
-    return prefetch_many(ctx, n, dirs, metrics, normal_modes, ctx->world > 1);
+    return prefetch_many(ctx, n, dirs, metrics, normal_modes, ctx->sharded());
 }
 
 static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, bool want_units)
@@ -1098,7 +1137,7 @@ int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
     NOT_CAPTURING(ctx);
     if (!out) return fail(PCCM_E_ARG, "null pointer");
     if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
-    if (ctx->world != 1) return fail(PCCM_E_STATE, "pccm_reduce_total needs the whole column on this GPU (world = 1)");
+    if (ctx->sharded()) return fail(PCCM_E_STATE, "pccm_reduce_total needs the whole column on this GPU (world = 1)");
     ReduceSlot *s = slot_find(ctx, dir, metric, normal_mode);
     if (!s) {
         int rc = pccm_reduce_prefetch(ctx, dir, metric, normal_mode);
@@ -1340,8 +1379,10 @@ int pccm_ctx_reset(pccm_ctx *ctx)
         drop_cloud(ctx->cloud[k]);
         ctx->cloud[k].version++;
     }
-    ctx->rank = 0;
-    ctx->world = 1;
+    for (int d = 0; d < 3; ++d) {
+        ctx->shard_rank[d] = 0;
+        ctx->shard_world[d] = 1;
+    }
     for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
     for (auto &s : ctx->slots) s.pending = false;
     for (auto &g : ctx->graphs) graph_free(g);

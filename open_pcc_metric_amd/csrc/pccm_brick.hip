@@ -30,26 +30,28 @@
 
 namespace pccm {
 
-constexpr int kBY = 4, kBZ = 2;
-constexpr int kNRow = kBY * kBZ;                     // query rows of a brick
-constexpr int kNRun = (kBY + 2) * (kBZ + 2);         // staged x-runs
 constexpr int kBXMax = 64;
 constexpr int kLcsPitch = kBXMax + 3;                // cell starts per staged run (BX + 2 cells + 1), odd pitch
-constexpr int kBrickCap = 2560;                      // staged records per brick: 40 KB of LDS (+ 6.5 KB of cell starts)
 constexpr float kBigF = 3.0e38f;
 
 struct BrickParams {
     int bx;                 // cells per brick along x
     int nbx, nby, nbz;      // bricks per axis
     int64_t per_job;        // nbx * nby * nbz
-    int cap;                // staged records that fit
+    int cap;                // staged records that fit (< 65536: LDS positions are kept as uint16)
 };
 
-template <bool SELF>
-__global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g, BrickParams bp)
+// NT threads per workgroup, brick of BX x BY x BZ cells.  Occupancy is set by LDS (16 B per staged record), so the
+// kernel spends registers freely: the next query of a lane and its row-indexed normal are in flight while the
+// current one is scanned.
+template <bool SELF, int NT, int BY, int BZ>
+__global__ __launch_bounds__(NT) void k_brick_query(QueryJobs jobs, GridGeom g, BrickParams bp)
 {
+    constexpr int kNRow = BY * BZ;                   // query rows of a brick
+    constexpr int kNRun = (BY + 2) * (BZ + 2);       // staged x-runs
+    static_assert(kNRun <= 64 && kNRow <= 64, "one wave scans the run / row lengths");
     extern __shared__ float4 s_rec[];                // [cap + 1]
-    __shared__ uint32_t s_lcs[kNRun * kLcsPitch];
+    __shared__ uint16_t s_lcs[kNRun * kLcsPitch];
     __shared__ uint32_t s_g0[kNRun], s_base[kNRun + 1], s_qg0[kNRow], s_qoff[kNRow + 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // XCD-aware order: workgroups b, b+8, ... share an XCD; give every XCD one contiguous eighth of the brick list
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
     const int ibx = (int)(vb % bp.nbx), iby = (int)((vb / bp.nbx) % bp.nby), ibz = (int)(vb / ((int64_t)bp.nbx * bp.nby));
     const int bx0 = ibx * bp.bx, bx1 = min(bx0 + bp.bx, dimx);
-    const int by0 = iby * kBY, bz0 = ibz * kBZ;
+    const int by0 = iby * BY, bz0 = ibz * BZ;
     const int sx0 = max(bx0 - 1, 0), sx1 = min(bx1 + 1, dimx);
     const int ncs = sx1 - sx0;                                        // staged cells per run, <= bx + 2
     const uint32_t *__restrict__ cs = J.cs;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
     if (w == 0) {
         uint32_t len = 0, g0 = 0;
         if (lane < kNRun) {
-            const int y = by0 - 1 + lane % (kBY + 2), z = bz0 - 1 + lane / (kBY + 2);
+            const int y = by0 - 1 + lane % (BY + 2), z = bz0 - 1 + lane / (BY + 2);
             if (y >= 0 && y < dimy && z >= 0 && z < dimz) {
                 const uint32_t rowbase = ((uint32_t)z * dimy + y) * dimx;
                 g0 = cs[rowbase + sx0];
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
         }
         uint32_t inc = len;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
+        for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off);
             if (lane >= off) inc += o;
         }
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
     } else if (w == 1) {
         uint32_t len = 0, q0 = 0;
         if (lane < kNRow) {
-            const int y = by0 + lane % kBY, z = bz0 + lane / kBY;
+            const int y = by0 + lane % BY, z = bz0 + lane / BY;
             if (y < dimy && z < dimz) {
                 const uint32_t rowbase = ((uint32_t)z * dimy + y) * dimx;
                 q0 = qcs[rowbase + bx0];
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
         }
         uint32_t inc = len;
 #pragma unroll
-        for (int off = 1; off < kNRow; off <<= 1) {
+        for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off);
             if (lane >= off) inc += o;
         }
@@ -114,31 +116,50 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
     __syncthreads();
     const uint32_t T = s_base[kNRun], NQ = s_qoff[kNRow];
     if (NQ == 0) return;                                               // block-uniform
+
+    // query qi of the brick -> its row of the brick and its record
+    auto query_row = [&](uint32_t qi) {
+        int r = 0;
+#pragma unroll
+        for (int k = 1; k < kNRow; ++k) r += (qi >= s_qoff[k]) ? 1 : 0;
+        return r;
+    };
+    auto load_query = [&](uint32_t qi, int r) {
+        return *reinterpret_cast<const float4 *>(&qbase[s_qg0[r] + (qi - s_qoff[r])]);
+    };
+
     if (T > (uint32_t)bp.cap) {
         // clumped data: more candidates than the LDS budget holds -- the general kernels take this brick's queries
-        for (uint32_t qi = tid; qi < NQ; qi += 256) {
-            int r = 0;
-#pragma unroll
-            for (int k = 1; k < kNRow; ++k) r += (qi >= s_qoff[k]) ? 1 : 0;
-            const float4 q = *reinterpret_cast<const float4 *>(&qbase[s_qg0[r] + (qi - s_qoff[r])]);
+        for (uint32_t qi = tid; qi < NQ; qi += NT) {
+            const float4 q = load_query(qi, query_row(qi));
             const uint32_t pos = atomicAdd(&J.counters[1], 1u);
             reinterpret_cast<float4 *>(J.tail)[pos] = q;
         }
         return;
     }
 
-    // ---- 2. stage cell starts (wave w: runs w, w+4, ...) and records (interleaved 64-record pieces) ---------
-    for (int r = w; r < kNRun; r += 4) {
-        const int y = by0 - 1 + r % (kBY + 2), z = bz0 - 1 + r / (kBY + 2);
+    // the lane's first query is fetched while the brick is staged
+    uint32_t qi = tid;
+    bool have = qi < NQ;
+    int rn = 0;
+    float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have) {
+        rn = query_row(qi);
+        qn = load_query(qi, rn);
+    }
+
+    // ---- 2. stage cell starts (wave w: runs w, w + NT/64, ...) and records (interleaved 64-record pieces) -------
+    for (int r = w; r < kNRun; r += NT / 64) {
+        const int y = by0 - 1 + r % (BY + 2), z = bz0 - 1 + r / (BY + 2);
         const bool in = y >= 0 && y < dimy && z >= 0 && z < dimz;      // wave-uniform
         const uint32_t rowbase = in ? ((uint32_t)z * dimy + y) * dimx : 0u;
         const uint32_t rebase = s_base[r] - s_g0[r];
         for (int j = lane; j <= ncs; j += 64)
-            s_lcs[r * kLcsPitch + j] = in ? cs[rowbase + sx0 + j] + rebase : s_base[r];
+            s_lcs[r * kLcsPitch + j] = (uint16_t)(in ? cs[rowbase + sx0 + j] + rebase : s_base[r]);
     }
     {
         int run = 0;                                                   // wave-uniform, monotone
-        for (uint32_t f0 = (uint32_t)w * 64u; f0 < T; f0 += 256u) {
+        for (uint32_t f0 = (uint32_t)w * 64u; f0 < T; f0 += (uint32_t)NT) {
             while (run + 1 < kNRun && f0 >= s_base[run + 1]) ++run;
             const uint32_t f = f0 + lane;
             int myrun = run;
@@ -146,29 +167,38 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
             if (f < T) s_rec[f] = *reinterpret_cast<const float4 *>(&srecs[s_g0[myrun] + (f - s_base[myrun])]);
         }
     }
+    const NNOut &out = J.out;
+    const bool fuse = out.nrm != nullptr;
+    const bool fuse_row = fuse && out.normal_mode == PCCM_NORMAL_ROW;
+    // row-indexed normal (quirk Q1) of the first query: its address is known as soon as the query is here
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    if (have && fuse_row) {
+        const double *np = out.nrm + 3 * (int64_t)__float_as_int(qn.w);
+        n0 = np[0]; n1 = np[1]; n2 = np[2];
+    }
     __syncthreads();
 
     // ---- 3. queries ------------------------------------------------------------------------------------------
-    const NNOut &out = J.out;
-    for (uint32_t q0 = 0; q0 < NQ; q0 += 256u) {
-        const uint32_t qi = q0 + tid;
-        if (qi >= NQ) break;                                           // no barrier below: lanes may leave
-        int r = 0;
-#pragma unroll
-        for (int k = 1; k < kNRow; ++k) r += (qi >= s_qoff[k]) ? 1 : 0;
-        const float4 q = *reinterpret_cast<const float4 *>(&qbase[s_qg0[r] + (qi - s_qoff[r])]);
+    while (have) {                                                     // no barrier below: lanes may leave
+        const float4 q = qn;
+        const int r = rn;
+        const double m0 = n0, m1 = n1, m2 = n2;
         const int qrow = __float_as_int(q.w);
+        // next query of this lane, and its normal: in flight during the scan
+        const uint32_t qnext = qi + NT;
+        const bool hn = qnext < NQ;
+        if (hn) {
+            rn = query_row(qnext);
+            qn = load_query(qnext, rn);
+            if (fuse_row) {
+                const double *np = out.nrm + 3 * (int64_t)__float_as_int(qn.w);
+                n0 = np[0]; n1 = np[1]; n2 = np[2];
+            }
+        }
         const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
-        const int ly = r % kBY, lz = r / kBY;
+        const int ly = r % BY, lz = r / BY;
         const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
         const int cy = by0 + ly, cz = bz0 + lz;
-        // row-indexed normal (quirk Q1): its address is known now; issue the gather before the scan
-        double n0 = 0.0, n1 = 0.0, n2 = 0.0;
-        const bool fuse = out.nrm != nullptr;
-        if (fuse && out.normal_mode == PCCM_NORMAL_ROW) {
-            const double *np = out.nrm + 3 * (int64_t)qrow;
-            n0 = np[0]; n1 = np[1]; n2 = np[2];
-        }
         const int ja = max(cx - 1, 0) - sx0, jb2 = min(cx + 2, dimx) - sx0;
         float best = kBigF, second = kBigF;
         uint32_t bestpos = 0xffffffffu;
@@ -176,10 +206,17 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
         for (int dz = 0; dz < 3; ++dz) {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                const int run = (lz + dz) * (kBY + 2) + (ly + dy);
+                const int run = (lz + dz) * (BY + 2) + (ly + dy);
                 const uint32_t fs = s_lcs[run * kLcsPitch + ja], fe = s_lcs[run * kLcsPitch + jb2];
                 for (uint32_t f = fs; f < fe; f += 2) {
-                    const float4 c0 = s_rec[f], c1 = s_rec[f + 1];     // slot f + 1 always exists (cap + 1 slots)
+                    // two records = 32 contiguous bytes: two ds_read_b128 (4 LDS cycles each).  Left to itself hipcc
+                    // drops the unused row word and issues ds_read_b96, which the LDS serves at 8 cycles per wave
+                    // (MI355X_MICROARCH.md, LDS table): the reads, not the arithmetic, then pace the loop.
+                    float4 c0, c1;                                     // slot f + 1 always exists (cap + 1 slots)
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(c0), "=&v"(c1)
+                                 : "v"((uint32_t)(uintptr_t)(&s_rec[f]))
+                                 : "memory");
                     const bool two = f + 1 < fe;
                     const float ax = q.x - c0.x, ay = q.y - c0.y, az = q.z - c0.z;
                     const float bx = q.x - c1.x, by = q.y - c1.y, bz = q.z - c1.z;
@@ -217,14 +254,15 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
             if (settled) {
                 double p = 0.0;
                 if (fuse) {
-                    if (out.normal_mode != PCCM_NORMAL_ROW) {
+                    double e0 = m0, e1 = m1, e2 = m2;
+                    if (!fuse_row) {
                         const double *np = out.nrm + 3 * (int64_t)wrow;
-                        n0 = np[0]; n1 = np[1]; n2 = np[2];
+                        e0 = np[0]; e1 = np[1]; e2 = np[2];
                     }
                     const double ex = __dsub_rn(qx, rx), ey = __dsub_rn(qy, ry), ez = __dsub_rn(qz, rz);
-                    p = __dmul_rn(ex, n0);
-                    p = __fma_rn(ey, n1, p);
-                    p = __fma_rn(ez, n2, p);
+                    p = __dmul_rn(ex, e0);
+                    p = __fma_rn(ey, e1, p);
+                    p = __fma_rn(ez, e2, p);
                 }
                 double4 o;
                 o.x = d64;
@@ -238,13 +276,49 @@ __global__ __launch_bounds__(256) void k_brick_query(QueryJobs jobs, GridGeom g,
             const uint32_t pos = atomicAdd(&J.counters[1], 1u);
             reinterpret_cast<float4 *>(J.tail)[pos] = q;
         }
+        qi = qnext;
+        have = hn;
     }
 }
 
-bool brick_applicable(const GridGeom &g)
+// brick shape / workgroup size: PCCM_BRICK="NT,BY,BZ" picks one of the compiled variants (A/B runs)
+struct BrickShape {
+    int nt, by, bz;
+};
+
+static BrickShape brick_shape()
 {
-    (void)g;
-    return true;
+    static const BrickShape s = [] {
+        BrickShape v = {512, 4, 2};
+        const char *e = getenv("PCCM_BRICK");
+        if (e) {
+            int a = 0, b = 0, c = 0;
+            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) v = {a, b, c};
+        }
+        return v;
+    }();
+    return s;
+}
+
+template <int NT, int BY, int BZ>
+static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density)
+{
+    bp.nby = (g.dim[1] + BY - 1) / BY;
+    bp.nbz = (g.dim[2] + BZ - 1) / BZ;
+    bp.per_job = (int64_t)bp.nbx * bp.nby * bp.nbz;
+    // LDS budget: the expected number of staged records (runs x cells x points per cell) plus a quarter -- occupancy
+    // is set by it.  Bricks that hold more (clumped data) hand their queries to the general kernels.
+    const double expect = (double)((BY + 2) * (BZ + 2)) * (bp.bx + 2) * density;
+    int cap = (int)(1.25 * expect) + 64;
+    static const int cap_env = [] { const char *e = getenv("PCCM_BRICK_CAP"); return e ? atoi(e) : 0; }();
+    if (cap_env > 0) cap = cap_env;
+    if (cap < 256) cap = 256;
+    if (cap > 3800) cap = 3800;                         // 60 KB of records: static + dynamic LDS stay under 64 KB
+    bp.cap = cap;
+    const size_t lds = (size_t)(bp.cap + 1) * sizeof(float4);
+    dim3 grid((unsigned)(bp.per_job * jobs.njobs));
+    if (self) hipLaunchKernelGGL((k_brick_query<true, NT, BY, BZ>), grid, dim3(NT), lds, ctx->stream, jobs, g, bp);
+    else hipLaunchKernelGGL((k_brick_query<false, NT, BY, BZ>), grid, dim3(NT), lds, ctx->stream, jobs, g, bp);
 }
 
 int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self)
@@ -254,16 +328,18 @@ int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, 
     bp.bx = (g.dim[0] + nbx - 1) / nbx;
     if (bp.bx > kBXMax) bp.bx = kBXMax;
     bp.nbx = (g.dim[0] + bp.bx - 1) / bp.bx;
-    bp.nby = (g.dim[1] + kBY - 1) / kBY;
-    bp.nbz = (g.dim[2] + kBZ - 1) / kBZ;
-    bp.per_job = (int64_t)bp.nbx * bp.nby * bp.nbz;
-    bp.cap = kBrickCap;
-    const int64_t nblk = bp.per_job * jobs.njobs;
-    if (nblk > 0x7fffffffLL) return fail(PCCM_E_ARG, "grid too large for the brick kernel");
-    const size_t lds = (size_t)(bp.cap + 1) * sizeof(float4);
-    dim3 grid((unsigned)nblk);
-    if (self) hipLaunchKernelGGL((k_brick_query<true>), grid, dim3(256), lds, ctx->stream, jobs, g, bp);
-    else hipLaunchKernelGGL((k_brick_query<false>), grid, dim3(256), lds, ctx->stream, jobs, g, bp);
+    bp.nby = bp.nbz = 0;
+    bp.per_job = 0;
+    bp.cap = 0;
+    const Grid &gr = ctx->grid;
+    const int64_t nmax = gr.n[0] > gr.n[1] ? gr.n[0] : gr.n[1];
+    const double density = gr.ncells > 0 ? (double)nmax / (double)gr.ncells : 1.5;      // points per cell of the denser cloud
+    const BrickShape sh = brick_shape();
+    if (sh.nt == 256 && sh.by == 4 && sh.bz == 2) launch_shape<256, 4, 2>(ctx, jobs, g, self, bp, density);
+    else if (sh.nt == 256 && sh.by == 2 && sh.bz == 2) launch_shape<256, 2, 2>(ctx, jobs, g, self, bp, density);
+    else if (sh.nt == 512 && sh.by == 4 && sh.bz == 4) launch_shape<512, 4, 4>(ctx, jobs, g, self, bp, density);
+    else if (sh.nt == 1024 && sh.by == 4 && sh.bz == 4) launch_shape<1024, 4, 4>(ctx, jobs, g, self, bp, density);
+    else launch_shape<512, 4, 2>(ctx, jobs, g, self, bp, density);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }

@@ -101,8 +101,9 @@ struct BuildJobs {
     int64_t total;
 };
 
-// Counting sort of the jobs' rows by cell into `recs` (positions run across the jobs); on return every job's
-// cs[c] holds the position of the first record of cell c and cs[ncells] the end of the job's records.
+// Counting sort of the jobs' rows by cell into `recs` (job 0's records, then job 1's); on return every job's
+// cs[c] holds the position of the first record of cell c RELATIVE to the job's first record and cs[ncells] the
+// number of records of the job.
 int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_t ncells, void *recs, bool rec32);
 
 // scratch sizes (so that callers can allocate before a graph capture)
@@ -156,11 +157,11 @@ __device__ __forceinline__ void emit_result_lookup(const NNOut &o, const double 
 // ---- query jobs (pccm_grid.hip launches; pccm_brick.hip holds the LDS-brick kernel) ----------------------
 struct QueryJob {
     const void *qrecs;          // cell-sorted queries of this job, [nq] (GridRec or Rec32: Grid::rec32)
-    const void *qbase;          // array the query cloud's cell starts index (qrecs = qbase + first position)
+    const void *qbase;          // first record of the query cloud / shard: what its cell starts (qcs) index
     const uint32_t *qcs;        // query cloud's (or shard's) cell starts
     int64_t nq, nchunks;        // nchunks = ceil(nq / 64)
     const uint32_t *cs;         // searched cloud's cell starts (positions in srecs)
-    const void *srecs;          // combined record array
+    const void *srecs;          // searched cloud's records
     const double *s64;          // searched cloud's fp64 rows (emit_result_lookup)
     int64_t row_base;           // first row of the shard (outputs are indexed row - row_base)
     double slack32;             // fp32 rounding slack of inexact inputs (see pccm_brute.hip); 0 = both clouds fp32-exact
@@ -199,6 +200,5 @@ __device__ __forceinline__ bool settled_by(double L, double d)
 
 // LDS-brick ring-1 kernel for Rec32 grids (pccm_brick.hip)
 int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self);
-bool brick_applicable(const GridGeom &g);
 
 }  // namespace pccm

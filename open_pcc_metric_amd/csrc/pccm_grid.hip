@@ -801,12 +801,14 @@ static bool pair_rec32(const pccm_ctx *ctx)
 
 // (re)build the combined grid when either cloud changed, the caches were dropped or the record layout asked for
 // differs from the built one (need64: a caller that reads GridRec records, pccm_normals.hip)
-static int ensure_grid(pccm_ctx *ctx, bool need64 = false)
+static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3)
 {
     Grid &gr = ctx->grid;
     const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
     const bool rec32 = !need64 && pair_rec32(ctx);
-    if (gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p && gr.rec32 == rec32) return PCCM_OK;
+    const bool same = gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p && gr.rec32 == rec32;
+    if (same && (gr.built & need_mask) == need_mask) return PCCM_OK;
+    if (same) need_mask |= gr.built;                   // keep what is there, add what is missing
     int rc0 = decide_scale(ctx, key);
     if (rc0) return rc0;
     ProfScope ps(ctx, PCCM_K_GRID_BUILD);
@@ -818,12 +820,21 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false)
     if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;   // either layout fits
     uint32_t *cs = (uint32_t *)gr.cell_start.p;
+    const size_t rsz = rec32 ? sizeof(Rec32) : sizeof(GridRec);
+    // cloud k's records live at recs + (k ? n0 : 0) whichever clouds are built; cell starts are relative to that
     BuildJobs jobs;
-    jobs.njobs = 2;
-    jobs.j[0] = {ctx->cloud[0].xyz64, (const float *)ctx->cloud[0].xyz32, 0, n0, cs};
-    jobs.j[1] = {ctx->cloud[1].xyz64, (const float *)ctx->cloud[1].xyz32, 0, n1, cs + ncells + 1};
-    jobs.total = n0 + n1;
-    if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, ncells, gr.recs.p, rec32))) return rc;
+    jobs.njobs = 0;
+    jobs.total = 0;
+    char *first = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        if (!(need_mask & (1 << k))) continue;
+        const Cloud &c = ctx->cloud[k];
+        if (jobs.njobs == 0) first = (char *)gr.recs.p + (size_t)(k ? n0 : 0) * rsz;
+        jobs.j[jobs.njobs++] = {c.xyz64, (const float *)c.xyz32, 0, c.n, cs + (size_t)k * (ncells + 1)};
+        jobs.total += c.n;
+    }
+    if (jobs.njobs == 1) jobs.j[1] = jobs.j[0];
+    if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, ncells, first, rec32))) return rc;
     for (int a = 0; a < 3; ++a) {
         gr.dim[a] = g.dim[a];
         gr.org[a] = g.org[a];
@@ -835,6 +846,7 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false)
     gr.n[1] = n1;
     gr.key = key;
     gr.rec32 = rec32;
+    gr.built = need_mask;
     return PCCM_OK;
 }
 
@@ -913,7 +925,13 @@ int grid_prefers_brute(pccm_ctx *ctx, bool *yes)
 {
     int rc;
     *yes = false;
-    if ((rc = ensure_grid(ctx))) return rc;
+    if (ctx->grid.iso_key == ctx->grid.scale_key && ctx->grid.scale_key != 0) {     // verdict already known for this pair
+        Grid &g0 = ctx->grid;
+        for (int ii = 0; ii < 2; ++ii)
+            if (g0.n[ii] > 0 && (double)g0.isolated[ii] > 0.03 * (double)g0.n[ii] && g0.isolated[ii] > 64) *yes = true;
+        return PCCM_OK;
+    }
+    if ((rc = ensure_grid(ctx))) return rc;             // both clouds: the count looks at both directions
     if ((rc = check_isolation(ctx))) return rc;
     Grid &gr = ctx->grid;
     for (int ii = 0; ii < 2; ++ii)
@@ -952,7 +970,21 @@ static void launch_queries(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom 
 int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
 {
     int rc;
-    if ((rc = ensure_grid(ctx))) return rc;
+    // which clouds' search structures this call needs: the searched cloud of every direction with rows here, and the
+    // iterating cloud when all of its rows are here (its cell-sorted records are the query list then)
+    int need = 0;
+    for (int d = 0; d < ndirs; ++d) {
+        const NNResult &res = ctx->nn[dirs[d]];
+        if (res.end <= res.begin) continue;
+        const int si = (dirs[d] == PCCM_DIR_LEFT) ? 1 : 0, ii = (dirs[d] == PCCM_DIR_RIGHT) ? 1 : 0;
+        need |= 1 << si;
+        if (res.begin == 0 && res.end == ctx->cloud[ii].n) need |= 1 << ii;
+    }
+    if (need == 0) {                                       // no rows of these directions on this rank
+        for (int d = 0; d < ndirs; ++d) PCCM_HIP(hipMemsetAsync(ctx->nn[dirs[d]].nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
+        return PCCM_OK;
+    }
+    if ((rc = ensure_grid(ctx, false, need))) return rc;
     const Grid &gr = ctx->grid;
     const GridGeom g = geom_of(gr);
     const uint32_t *cs_all = (const uint32_t *)gr.cell_start.p;
@@ -988,7 +1020,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         QueryJob J;
         if (res.begin == 0 && res.end == it.n) {
             J.qrecs = recs_all + (size_t)(ii ? gr.n[0] : 0) * rsz;   // whole cloud: its own cell-sorted records
-            J.qbase = recs_all;
+            J.qbase = J.qrecs;
             J.qcs = cs_all + (ii ? gr.ncells + 1 : 0);
         } else {
             // shard: its rows are sorted by the same cells into the shared shard-record buffer (below, one
@@ -1006,7 +1038,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         J.nq = nq;
         J.nchunks = (nq + 63) / 64;
         J.cs = cs_all + (si ? gr.ncells + 1 : 0);
-        J.srecs = recs_all;
+        J.srecs = recs_all + (size_t)(si ? gr.n[0] : 0) * rsz;
         J.s64 = se.xyz64;
         J.row_base = res.begin;
         J.slack32 = exact ? 0.0 : maxabs * 0x1.0p-20;
@@ -1052,7 +1084,6 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
                 bj.total += res.end - res.begin;
             }
             if (cnt == 1) bj.j[1] = bj.j[0];
-            // positions run across the jobs of one sort, i.e. they index qbuf + shard_off[s0]
             if ((rc = sort_by_cell(ctx, bj, g, gr.ncells, qbuf + (size_t)shard_off[s0] * rsz, gr.rec32))) return rc;
         }
         for (int s = 0; s < nshard; ++s) {
@@ -1060,7 +1091,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
             QueryJobs &dst = (dir == PCCM_DIR_SELF) ? selfj : normal;
             QueryJob &J = dst.j[job_of_dir[dir]];
             J.qrecs = qbuf + (size_t)shard_off[s] * rsz;
-            J.qbase = qbuf + (size_t)shard_off[s & ~1] * rsz;        // base of the sort this shard took part in
+            J.qbase = J.qrecs;                                       // cell starts are relative to the shard's first record
             J.qcs = (const uint32_t *)ctx->g_hist.p + (size_t)s * (gr.ncells + 1);
         }
     }
@@ -1129,6 +1160,6 @@ void grid_release(pccm_ctx *ctx)
 
 void grid_invalidate(pccm_ctx *ctx) { ctx->grid.key = 0; }
 
-int grid_ensure(pccm_ctx *ctx, bool need64) { return ensure_grid(ctx, need64); }
+int grid_ensure(pccm_ctx *ctx, bool need64, int need_mask) { return ensure_grid(ctx, need64, need_mask); }
 
 }  // namespace pccm

@@ -270,8 +270,15 @@ __device__ __forceinline__ void block_scan_inplace(uint32_t *s_cnt, int nc, uint
     }
 }
 
+// raw records (no widening to fp64 in registers: the bin's records wait in VGPRs while the cells are counted)
+__device__ __forceinline__ uint32_t rec_cell(const GridGeom &g, const float4 &r) { return cell_linear(g, (double)r.x, (double)r.y, (double)r.z); }
+__device__ __forceinline__ uint32_t rec_cell(const GridGeom &g, const double4 &r) { return cell_linear(g, r.x, r.y, r.z); }
+template <typename REC> struct RawRec;
+template <> struct RawRec<Rec32> { typedef float4 type; };
+template <> struct RawRec<GridRec> { typedef double4 type; };
+
 template <typename REC>
-__global__ __launch_bounds__(256) void k_bin_sort(BinPlan P, GridGeom g, const uint32_t *__restrict__ hist, const REC *__restrict__ tmp,
+__global__ __launch_bounds__(256, sizeof(REC) == 16 ? 6 : 4) void k_bin_sort(BinPlan P, GridGeom g, const uint32_t *__restrict__ hist, const REC *__restrict__ tmp,
                                                   REC *__restrict__ recs)
 {
     extern __shared__ uint32_t s_cnt[];                   // [cells of a bin]
@@ -282,31 +289,35 @@ __global__ __launch_bounds__(256) void k_bin_sort(BinPlan P, GridGeom g, const u
     const BinJob &J = P.j[jb];
     const uint32_t s = hist[J.hoff + (int64_t)b * J.nt], e = hist[J.hoff + (int64_t)(b + 1) * J.nt];
     const uint32_t m = e - s;
+    const uint32_t j0 = hist[J.hoff];                     // first record of this job: cell starts are relative to it
     const int64_t c0 = (int64_t)b << P.lg;
     const int nc = (int)((c0 + (1ll << P.lg) < P.ncells ? c0 + (1ll << P.lg) : P.ncells) - c0);
     for (int c = tid; c < nc; c += 256) s_cnt[c] = 0u;
     __syncthreads();
     if (m <= (uint32_t)kRegRecs) {
         // the whole bin in registers: rank by the counting atomic, place after the scan
-        P3 v[kRegK];
+        typedef typename RawRec<REC>::type RAW;
+        const RAW *__restrict__ src = reinterpret_cast<const RAW *>(tmp);
+        RAW *__restrict__ dst = reinterpret_cast<RAW *>(recs);
+        RAW v[kRegK];
         uint32_t cell[kRegK], rank[kRegK];
 #pragma unroll
         for (int k = 0; k < kRegK; ++k) {
             const uint32_t i = tid + 256u * k;
-            if (i < m) {
-                v[k] = load_rec(tmp, s + i);
-                cell[k] = cell_linear(g, v[k].x, v[k].y, v[k].z) - (uint32_t)c0;
-            }
+            if (i < m) v[k] = src[s + i];
         }
 #pragma unroll
         for (int k = 0; k < kRegK; ++k)
-            if (tid + 256u * k < m) rank[k] = atomicAdd(&s_cnt[cell[k]], 1u);
+            if (tid + 256u * k < m) {
+                cell[k] = rec_cell(g, v[k]) - (uint32_t)c0;
+                rank[k] = atomicAdd(&s_cnt[cell[k]], 1u);
+            }
         __syncthreads();
         block_scan_inplace(s_cnt, nc, s_wsum, &s_carry);
-        for (int c = tid; c < nc; c += 256) J.cs[c0 + c] = s + s_cnt[c];
+        for (int c = tid; c < nc; c += 256) J.cs[c0 + c] = s - j0 + s_cnt[c];
 #pragma unroll
         for (int k = 0; k < kRegK; ++k)
-            if (tid + 256u * k < m) store_rec(recs, s + s_cnt[cell[k]] + rank[k], v[k]);
+            if (tid + 256u * k < m) dst[s + s_cnt[cell[k]] + rank[k]] = v[k];
     } else {
         for (uint32_t i = tid; i < m; i += 256) {
             const P3 v = load_rec(tmp, s + i);
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(BinPlan P, GridGeom g, const u
         }
         __syncthreads();
         block_scan_inplace(s_cnt, nc, s_wsum, &s_carry);
-        for (int c = tid; c < nc; c += 256) J.cs[c0 + c] = s + s_cnt[c];
+        for (int c = tid; c < nc; c += 256) J.cs[c0 + c] = s - j0 + s_cnt[c];
         __syncthreads();                                   // cell_start is out: the offsets become cursors
         for (uint32_t i = tid; i < m; i += 256) {
             const P3 v = load_rec(tmp, s + i);
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(BinPlan P, GridGeom g, const u
             store_rec(recs, s + pos, v);
         }
     }
-    if (b == P.nbin - 1 && tid == 0) J.cs[P.ncells] = e;  // end of the job's records
+    if (b == P.nbin - 1 && tid == 0) J.cs[P.ncells] = e - j0;   // number of records of the job
 }
 
 static int ceil_log2(int64_t v)
@@ -347,7 +358,8 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
         BinJob &d = P.j[k];
         d.x64 = s.x64; d.x32 = s.x32; d.row0 = s.row0; d.cs = s.cs;
         d.n = k < jobs.njobs ? s.n : 0;
-        int64_t nt = (d.n + 2047) / 2048;
+        static const int64_t tile_rows = [] { const char *e = getenv("PCCM_BUILD_TILE"); int64_t v = e ? atoll(e) : 2048; return v >= 256 ? v : 2048; }();
+        int64_t nt = (d.n + tile_rows - 1) / tile_rows;
         if (nt > 1024) nt = 1024;
         d.nt = nt;
         d.tl = nt > 0 ? ((d.n + nt - 1) / nt + 255) / 256 * 256 : 256;

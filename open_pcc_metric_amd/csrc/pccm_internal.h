@@ -102,6 +102,8 @@ struct Grid {                    // one geometry, both clouds (grid engine)
     uint64_t iso_key = 0;          // pair the isolation count below was taken for
     int64_t isolated[2] = {0, 0};  // points of cloud k with nothing of the other cloud within kMaxRing cells
     bool rec32 = false;            // records are Rec32 (both clouds fp32-exact) instead of GridRec
+    int built = 0;                 // bit k: cloud k's records and cell starts are built (a rank that searches one direction
+                                   // of a sharded pair builds only the cloud it searches)
     int dim[3] = {1, 1, 1};
     double org[3] = {0, 0, 0};
     double h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};   // cell edge per axis
@@ -153,7 +155,10 @@ struct pccm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     pccm::Cloud cloud[2];
-    int rank = 0, world = 1;
+    // query-axis shard per direction (pccm_set_shard / pccm_set_shard_dir): this context owns the rows shard_of(n, rank,
+    // world) of the iterating cloud; world 0 = none of them (another group of ranks searches that direction)
+    int shard_rank[3] = {0, 0, 0}, shard_world[3] = {1, 1, 1};
+    bool sharded() const { return shard_world[0] != 1 || shard_world[1] != 1 || shard_world[2] != 1; }
     pccm::NNResult nn[3];
     // scratch
     pccm::DevBuf part_b1, part_g, part_b2, val, stats, staging, counters;
@@ -215,7 +220,7 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
 int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs);
 void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
-int grid_ensure(pccm_ctx *ctx, bool need64 = false);   // need64: GridRec records wanted (pccm_normals.hip reads them)
+int grid_ensure(pccm_ctx *ctx, bool need64 = false, int need_mask = 3);   // need64: GridRec records wanted (pccm_normals.hip reads them)
 int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the current pair (cached per pair)
 int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)
 int estimate_normals(pccm_ctx *ctx, int which, int k);
@@ -256,16 +261,21 @@ struct PointJobs {
     int njobs;
     int64_t off[5];             // prefix sums of the jobs' row counts
 };
-struct UnitJob {                // one column to reduce (k_unit_jobs)
-    const double *val;          // element i at val[i * stride]
-    int stride;                 // in doubles: 1 = plain column, 4 = a field of the 32-byte result records
-    int square;                 // reduce val^2 (the D2 column from the records' signed projection; metric.py:179)
-    int64_t ns, nunits;
-    int64_t tail_first, tail_n; // rows [tail_first, tail_first + tail_n) are copied out raw
-    int64_t nblocks;            // ceil(nunits / 32)
+struct UnitCol {                // one column reduced from a job's array
+    int off;                    // field of the 32-byte result record (0: squared distance, 1: projection); 0 for plain columns
+    int square;                 // reduce value^2 (the D2 column from the records' signed projection; metric.py:179)
     double *out_units;          // pinned host memory [3][nunits] per-leaf sum/min/max, or null
     double *out_blocks;         // pinned host memory [3][nblocks] per-32-leaf tree sum/min/max
     double *out_tail;           // pinned host memory [tail_n]
+};
+struct UnitJob {                // one per-point array to reduce (k_unit_jobs): up to two columns per pass
+    const double *val;          // plain column (stride 1) or the result records (stride 4)
+    int stride;
+    int ncols;
+    UnitCol c[2];
+    int64_t ns, nunits;
+    int64_t tail_first, tail_n; // rows [tail_first, tail_first + tail_n) are copied out raw
+    int64_t nblocks;            // ceil(nunits / 32)
 };
 struct UnitJobs {
     UnitJob j[8];

@@ -417,7 +417,7 @@ int estimate_normals(pccm_ctx *ctx, int which, int k)
     if (c.n <= 0) return fail(PCCM_E_STATE, "cloud %d is not set", which);
     if (k < 3 || k > kKnnMax) return fail(PCCM_E_ARG, "k must be in 3..%d", kKnnMax);
     int rc;
-    if ((rc = grid_ensure(ctx, true))) return rc;      // this file reads GridRec (fp64) records
+    if ((rc = grid_ensure(ctx, true, 1 << which))) return rc;      // this file reads GridRec (fp64) records of one cloud
     const Grid &gr = ctx->grid;
     KnnGeom g;
     for (int a = 0; a < 3; ++a) {
@@ -440,15 +440,16 @@ int estimate_normals(pccm_ctx *ctx, int which, int k)
     PCCM_HIP(hipMemsetAsync(open_count, 0, 2 * sizeof(uint32_t), ctx->stream));
     double *cov = (double *)ctx->val.p;
     int32_t *cnt = (int32_t *)(cov + 6 * c.n);
-    // cell_start holds positions in the combined record array: pass the array base plus this cloud's offset
+    // cell_start holds positions relative to the cloud's first record
     const uint32_t *cs = (const uint32_t *)gr.cell_start.p + (which ? gr.ncells + 1 : 0);
-    const int64_t qbase = which ? gr.n[0] : 0;
+    const GridRec *crecs = (const GridRec *)gr.recs.p + (which ? gr.n[0] : 0);
+    const int64_t qbase = 0;
     const int64_t wblocks = (c.n + 3) / 4;
     hipLaunchKernelGGL(k_knn_cov_wave, dim3((unsigned)(wblocks < 16384 ? wblocks : 16384)), dim3(256), 0, ctx->stream,
-                       (const GridRec *)gr.recs.p, qbase, c.n, g, cs, k, cov, cnt, (uint32_t *)ctx->g_rank.p, todo_count);
+                       crecs, qbase, c.n, g, cs, k, cov, cnt, (uint32_t *)ctx->g_rank.p, todo_count);
     hipLaunchKernelGGL(k_normals_from_cov, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)cov,
                        (const int32_t *)cnt, c.n, c.nrm64);
-    hipLaunchKernelGGL(k_knn_normals, dim3(2048), dim3(256), 0, ctx->stream, (const GridRec *)gr.recs.p, qbase, g, cs,
+    hipLaunchKernelGGL(k_knn_normals, dim3(2048), dim3(256), 0, ctx->stream, crecs, qbase, g, cs,
                        (const double *)c.xyz64, k, c.nrm64, (const uint32_t *)ctx->g_rank.p, (const uint32_t *)todo_count,
                        (int32_t *)ctx->g_cell_of.p, open_count);
     hipLaunchKernelGGL(k_knn_normals_full, dim3(512), dim3(256), 0, ctx->stream, (const double *)c.xyz64, c.n, k,

@@ -232,9 +232,49 @@ int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs)
     return PCCM_OK;
 }
 
+// One job = one per-point array and up to TWO columns reduced from it in the same pass: a plain column (stride 1),
+// or fields of the grid engine's 32-byte result records (stride 4 doubles: [0] squared distance, [1] signed
+// projection) -- the D1 and D2 columns of a direction then cost one read of its records, 16 of every 32 bytes used.
+struct UnitView {               // the fields of a job the inner loop needs, in registers (wave-uniform)
+    const double *val;
+    int stride, off0, off1, sq0, sq1;
+};
+
+__device__ __forceinline__ UnitView unit_view(const UnitJob &J)
+{
+    UnitView w;
+    w.val = J.val;
+    w.stride = J.stride;
+    w.off0 = J.c[0].off; w.off1 = J.c[1].off;
+    w.sq0 = J.c[0].square; w.sq1 = J.c[1].square;
+    return w;
+}
+
+__device__ __forceinline__ void unit_load(const UnitView &J, int64_t i, double v[2])      // the load alone (callers batch them)
+{
+    if (J.stride == 4) {
+        const double2 t = *reinterpret_cast<const double2 *>(&J.val[i * 4]);
+        v[0] = t.x;
+        v[1] = t.y;
+    } else {
+        v[0] = v[1] = J.val[i];
+    }
+}
+
+__device__ __forceinline__ void unit_pick(const UnitView &J, double v[2])                 // fields -> the job's columns
+{
+    if (J.stride == 4) {
+        const double x = v[0], y = v[1];
+        v[0] = J.off0 ? y : x;
+        v[1] = J.off1 ? y : x;
+    }
+    if (J.sq0) v[0] = __dmul_rn(v[0], v[0]);
+    if (J.sq1) v[1] = __dmul_rn(v[1], v[1]);
+}
+
 __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
 {
-    __shared__ double ls[32], lmn[32], lmx[32];
+    __shared__ double ls[2][32], lmn[2][32], lmx[2][32];
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t unit_threads = jobs.uoff[jobs.njobs];
     if (t < unit_threads) {                                // block-uniform: jobs start at multiples of 256 lanes
@@ -242,89 +282,117 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
 #pragma unroll
         for (int k = 1; k < 8; ++k)
             if (k < jobs.njobs && t >= jobs.uoff[k]) jb = k;
+        jb = __builtin_amdgcn_readfirstlane(jb);              // block-uniform by construction: scalar loads of the job
         const UnitJob &J = jobs.j[jb];
+        const UnitView V = unit_view(J);
+        const int ncols = J.ncols;
         const int64_t u = (t - jobs.uoff[jb]) >> 3;
         const int k = threadIdx.x & 7, grp = threadIdx.x >> 3;
-        const double *__restrict__ val = J.val;
-        const int64_t st = J.stride;
-        const bool sq = J.square != 0;
         const int64_t base = u * kLeaf;
         const bool live = u < J.nunits;
         const int64_t cnt = !live ? 0 : ((J.ns - base < kLeaf) ? J.ns - base : kLeaf);
-        double r = 0.0, mn = INFINITY, mx = -INFINITY;
+        double r[2] = {0.0, 0.0}, mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
         if (cnt == kLeaf) {
-            double v[kLeaf / 8];
+            double v[kLeaf / 8][2];
+            // sixteen independent loads first; the layout test sits outside the loop so that they are issued together
+            if (V.stride == 4) {
 #pragma unroll
-            for (int j = 0; j < kLeaf / 8; ++j) v[j] = val[(base + 8 * j + k) * st];      // independent loads first
-            if (sq) {
+                for (int j = 0; j < kLeaf / 8; ++j) {
+                    const double2 t = *reinterpret_cast<const double2 *>(&V.val[(base + 8 * j + k) * 4]);
+                    v[j][0] = t.x;
+                    v[j][1] = t.y;
+                }
+            } else {
 #pragma unroll
-                for (int j = 0; j < kLeaf / 8; ++j) v[j] = __dmul_rn(v[j], v[j]);
+                for (int j = 0; j < kLeaf / 8; ++j) v[j][0] = v[j][1] = V.val[base + 8 * j + k];
             }
-            r = v[0];
-            mn = mx = r;
 #pragma unroll
-            for (int j = 1; j < kLeaf / 8; ++j) {
-                r = __dadd_rn(r, v[j]);
-                mn = fmin(mn, v[j]);
-                mx = fmax(mx, v[j]);
+            for (int j = 0; j < kLeaf / 8; ++j) unit_pick(V, v[j]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                r[c] = v[0][c];
+                mn[c] = mx[c] = r[c];
+#pragma unroll
+                for (int j = 1; j < kLeaf / 8; ++j) {
+                    r[c] = __dadd_rn(r[c], v[j][c]);
+                    mn[c] = fmin(mn[c], v[j][c]);
+                    mx[c] = fmax(mx[c], v[j][c]);
+                }
             }
         } else {
             for (int64_t e = k; e < cnt; e += 8) {
-                double v = val[(base + e) * st];
-                if (sq) v = __dmul_rn(v, v);
-                r = __dadd_rn(r, v);
-                mn = fmin(mn, v);
-                mx = fmax(mx, v);
+                double v[2];
+                unit_load(V, base + e, v);
+                unit_pick(V, v);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    r[c] = __dadd_rn(r[c], v[c]);
+                    mn[c] = fmin(mn[c], v[c]);
+                    mx[c] = fmax(mx[c], v[c]);
+                }
             }
         }
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            r = __dadd_rn(r, __shfl_xor(r, off));
-            mn = fmin(mn, __shfl_xor(mn, off));
-            mx = fmax(mx, __shfl_xor(mx, off));
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                r[c] = __dadd_rn(r[c], __shfl_xor(r[c], off));
+                mn[c] = fmin(mn[c], __shfl_xor(mn[c], off));
+                mx[c] = fmax(mx[c], __shfl_xor(mx[c], off));
+            }
         }
         if (k == 0) {
-            if (live && J.out_units) {                     // per-leaf results: the sharded exchange needs them
-                J.out_units[u] = r;
-                J.out_units[J.nunits + u] = mn;
-                J.out_units[2 * J.nunits + u] = mx;
+            for (int c = 0; c < ncols; ++c) {
+                double *ou = J.c[c].out_units;
+                if (live && ou) {                          // per-leaf results: the sharded exchange needs them
+                    ou[u] = r[c];
+                    ou[J.nunits + u] = mn[c];
+                    ou[2 * J.nunits + u] = mx[c];
+                }
             }
-            ls[grp] = r;
-            lmn[grp] = mn;
-            lmx[grp] = mx;
+            for (int c = 0; c < 2; ++c) {
+                ls[c][grp] = r[c];
+                lmn[c][grp] = mn[c];
+                lmx[c][grp] = mx[c];
+            }
         }
         __syncthreads();
-        if (threadIdx.x < 32) {
+        if (threadIdx.x < 64) {
             // this block's 32 leaves = one half of an 8192-row NumPy chunk when the shard starts on a chunk
             // boundary: finish NumPy's pairwise tree for the half here (adjacent pairs, five levels), so the
-            // host only adds 2 numbers per chunk instead of walking 64 leaves
-            double s = ls[threadIdx.x], a = lmn[threadIdx.x], b = lmx[threadIdx.x];
+            // host only adds 2 numbers per chunk instead of walking 64 leaves.  Lanes 0..31: column 0, 32..63: column 1.
+            const int c = threadIdx.x >> 5, l = threadIdx.x & 31;
+            double s = ls[c][l], a = lmn[c][l], b = lmx[c][l];
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) {
                 s = __dadd_rn(s, __shfl_xor(s, off));
                 a = fmin(a, __shfl_xor(a, off));
                 b = fmax(b, __shfl_xor(b, off));
             }
-            if (threadIdx.x == 0) {
+            if (l == 0 && c < ncols) {
                 const int64_t blk = (t - jobs.uoff[jb]) >> 8;
-                J.out_blocks[blk] = s;
-                J.out_blocks[J.nblocks + blk] = a;
-                J.out_blocks[2 * J.nblocks + blk] = b;
+                double *ob = J.c[c].out_blocks;
+                ob[blk] = s;
+                ob[J.nblocks + blk] = a;
+                ob[2 * J.nblocks + blk] = b;
             }
         }
         return;
     }
     // raw values of the last, partial 8192-row chunk (NumPy sums them with its own tree on the host)
-    const int64_t c = t - unit_threads;
-    if (c >= jobs.toff[jobs.njobs]) return;
+    const int64_t c0 = t - unit_threads;
+    if (c0 >= jobs.toff[jobs.njobs]) return;
     int jb = 0;
 #pragma unroll
     for (int k = 1; k < 8; ++k)
-        if (k < jobs.njobs && c >= jobs.toff[k]) jb = k;
+        if (k < jobs.njobs && c0 >= jobs.toff[k]) jb = k;
     const UnitJob &J = jobs.j[jb];
-    const int64_t e = c - jobs.toff[jb];
-    const double v = J.val[(J.tail_first + e) * J.stride];
-    J.out_tail[e] = J.square ? __dmul_rn(v, v) : v;
+    const UnitView V = unit_view(J);
+    const int64_t e = c0 - jobs.toff[jb];
+    double v[2];
+    unit_load(V, J.tail_first + e, v);
+    unit_pick(V, v);
+    for (int c = 0; c < J.ncols; ++c) J.c[c].out_tail[e] = v[c];
 }
 
 int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)

@@ -22,6 +22,7 @@ class OracleEngine:
         self.nrm = [None, None]
         self.rgb = [None, None]
         self.rank, self.world = 0, 1
+        self.dir_shard = {}            # direction -> (rank, world) set by set_shard_dir (world 0: owns nothing)
         self.res = {}
         self.method = method
         self.calls = []
@@ -90,6 +91,14 @@ class OracleEngine:
 
     def set_shard(self, rank, world):
         self.rank, self.world = rank, world
+        self.dir_shard = {}
+        self.res.clear()
+
+    def set_shard_dir(self, d, rank, world):
+        """pccm_set_shard_dir: per-direction row ownership (world 0: this rank owns no rows of d)."""
+        self.dir_shard[d] = (rank, world)
+        if world != 1:
+            self.world = max(self.world, 2)        # "sharded" for the checks that only ask whether there are peers
         self.res.clear()
 
     def n_iter(self, d):
@@ -97,8 +106,11 @@ class OracleEngine:
 
     def shard_range(self, d):
         n = self.n_iter(d)
+        rank, world = self.dir_shard.get(d, (self.rank, self.world))
+        if world <= 0:
+            return 0, 0
         units = (n + 127) // 128
-        return min(n, units * self.rank // self.world * 128), min(n, units * (self.rank + 1) // self.world * 128)
+        return min(n, units * rank // world * 128), min(n, units * (rank + 1) // world * 128)
 
     def _clouds(self, d):
         return {nat.DIR_LEFT: (0, 1), nat.DIR_RIGHT: (1, 0), nat.DIR_SELF: (0, 0)}[d]
@@ -109,6 +121,9 @@ class OracleEngine:
         b, e = self.shard_range(d)
         q = self.pts[it][b:e]
         self.calls.append(("nn", d))
+        if e == b:                                     # no rows of this direction on this rank
+            self.res[d] = (np.zeros(0, np.int64), np.zeros(0))
+            return
         if d == nat.DIR_SELF:
             if self.pts[0].shape[0] < 2:
                 self.res[d] = (np.full(e - b, -1, np.int64), np.zeros(e - b))

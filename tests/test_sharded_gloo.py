@@ -30,11 +30,11 @@ a = rng.random((n, 3), dtype=np.float32); b = rng.random((n + 37, 3), dtype=np.f
 na = rng.standard_normal((n, 3)); nb = rng.standard_normal((n + 37, 3))
 ca = rng.integers(0, 256, (n, 3)) / 255.0; cb = rng.integers(0, 256, (n + 37, 3)) / 255.0
 pair = CloudPair(PointCloud(a, na, ca), PointCloud(b, nb, cb), extent=[1, 1, 1], normal_index="neighbour",
-                 group=dist.group.WORLD, _engine=OracleEngine())
+                 group=dist.group.WORLD, shard_mode=os.environ["PCCM_MODE"], _engine=OracleEngine())
 res = MetricCalculator(pair).calculate(transform_options(CalculateOptions("ycc", True, True))).as_dict()
 col = np.asarray(pair.get_right_neighbour_distances())          # all-gathered column
 ev = np.asarray(pair.get_left_error_vector())
-out = {"rank": dist.get_rank(), "shard": pair._engine.shard_range(0),
+out = {"rank": dist.get_rank(), "shard": pair._engine.shard_range(0), "shards": [pair._engine.shard_range(d) for d in (0, 1, 2)],
        "rows": [[list(map(str, k)), [float(x).hex() for x in np.atleast_1d(v)]] for k, v in res.items()],
        "col_sum": float(np.sum(col)).hex(), "col_len": len(col), "ev_sum": float(np.sum(ev)).hex()}
 with open(os.path.join(os.environ["PCCM_OUT"], f"rank{dist.get_rank()}.json"), "w") as fh:
@@ -43,8 +43,9 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("n", [1000, 20011])
-def test_two_gloo_ranks_match_single_process(tmp_path, n):
+@pytest.mark.parametrize("n,world,mode", [(1000, 2, "direction"), (20011, 2, "direction"), (20011, 4, "direction"),
+                                          (20011, 8, "direction"), (5000, 3, "direction"), (20011, 2, "rows")])
+def test_gloo_ranks_match_single_process(tmp_path, n, world, mode):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from open_pcc_metric_amd.calculator import MetricCalculator
     from open_pcc_metric_amd.cloud_pair import CloudPair
@@ -54,20 +55,27 @@ def test_two_gloo_ranks_match_single_process(tmp_path, n):
 
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1", PCCM_OUT=str(tmp_path))
+    env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1", PCCM_OUT=str(tmp_path), PCCM_MODE=mode,
+               OMP_NUM_THREADS="2")
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
-    outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in (0, 1)]
-    assert sorted(o["rank"] for o in outs) == [0, 1]
-    assert outs[0]["rows"] == outs[1]["rows"]                      # both ranks hold the full result
-    shards = sorted(tuple(o["shard"]) for o in outs)
-    assert shards[0][0] == 0 and shards[0][1] == shards[1][0] and shards[1][1] == n and shards[0][1] % 128 == 0
+    outs = sorted((json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)), key=lambda o: o["rank"])
+    assert [o["rank"] for o in outs] == list(range(world))
+    assert all(o["rows"] == outs[0]["rows"] for o in outs)         # every rank holds the full result
+    # row ownership: for every direction the ranks' shards tile [0, n_iter) exactly once, in rank order, on 128-row units
+    for d, n_iter in ((0, n), (1, n + 37), (2, n)):
+        owned = [tuple(o["shards"][d]) for o in outs if o["shards"][d][1] > o["shards"][d][0]]
+        assert owned[0][0] == 0 and owned[-1][1] == n_iter
+        assert all(a[1] == b[0] and a[1] % 128 == 0 for a, b in zip(owned, owned[1:]))
+    if mode == "direction":
+        # the split is by direction first: no rank owns rows of both the left and the right direction
+        assert all(not (o["shards"][0][1] > o["shards"][0][0] and o["shards"][1][1] > o["shards"][1][0]) for o in outs)
 
     rng = np.random.default_rng(42)
     a = rng.random((n, 3), dtype=np.float32); b = rng.random((n + 37, 3), dtype=np.float32)
@@ -100,7 +108,8 @@ n = int(os.environ["PCCM_N"])
 rng = np.random.default_rng(7)
 a = rng.random((n + 300, 3), dtype=np.float32); b = rng.random((n, 3), dtype=np.float32)     # A larger than B
 na = rng.standard_normal((n + 300, 3)); nb = rng.standard_normal((n, 3))
-pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], group=dist.group.WORLD, _engine=OracleEngine())
+pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1, 1, 1], group=dist.group.WORLD,
+                 shard_mode=os.environ["PCCM_MODE"], _engine=OracleEngine())
 outcome = "no error"
 try:
     MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, False, True)))   # default normal_index="row"
@@ -112,14 +121,17 @@ dist.destroy_process_group()
 '''
 
 
-def test_row_indexed_normals_out_of_range_raise_on_every_rank(tmp_path):
+@pytest.mark.parametrize("mode", ["rows", "direction"])
+def test_row_indexed_normals_out_of_range_raise_on_every_rank(tmp_path, mode):
     """Reference quirk Q1 (metric.py:148-152: normals_other[i] with i up to len(iterating cloud)) under sharding:
     only the LAST rank's shard reaches past the other cloud's normals, yet every rank must raise the reference's
-    IndexError -- a per-shard decision would leave the low ranks waiting in the all-reduce."""
+    IndexError -- a per-shard decision would leave the low ranks waiting in the all-reduce.
+    Split by direction, the rank that searches the other direction owns no row of the offending column at all and must
+    raise just the same."""
     n = 3000
     script = tmp_path / "q1_worker.py"
     script.write_text(Q1_WORKER)
-    env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1", PCCM_OUT=str(tmp_path))
+    env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1", PCCM_OUT=str(tmp_path), PCCM_MODE=mode)
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -129,6 +141,9 @@ def test_row_indexed_normals_out_of_range_raise_on_every_rank(tmp_path):
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)       # a hang would trip the timeout
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     outs = [json.load(open(tmp_path / f"q1_rank{r}.json")) for r in (0, 1)]
-    assert outs[0]["shard"][1] <= n < outs[1]["shard"][1]          # rank 0's own rows are all in range, rank 1's are not
+    if mode == "rows":
+        assert outs[0]["shard"][1] <= n < outs[1]["shard"][1]      # rank 0's own rows are all in range, rank 1's are not
+    else:
+        assert outs[0]["shard"] == [0, n + 300] and outs[1]["shard"] == [0, 0]   # rank 1 owns no row of that column
     for o in outs:
         assert o["outcome"].startswith("IndexError"), o
