@@ -4,17 +4,23 @@
     python bench.py --gpus N --steps K --warmup W [--engine auto|brute|grid] [--points 1000000]
 
 One *step* = one pass of the hot path over one synthetic cloud pair already resident in HBM:
-both directional exact 1-NN sweeps (cloud_pair.py:67-78), the fused D1 and D2 point-to-plane
-columns, their np.sum / np.max reductions, the cross-rank exchange (N > 1) and the PSNR /
-symmetric aggregation on the host -- i.e. GeoMSE, GeoPSNR and GeoHausdorffDistance for
-point_to_plane in {False, True}, left, right and symmetric, evaluated through the product's own
-MetricCalculator DAG.  The PSNR peak (max extent of A's minimal OBB, CPU/Qhull code in the
-reference) is injected: it is not part of the GPU path (DESIGN.md section d).
+the search-structure build (the reference's two KD-tree builds, cloud_pair.py:65), both directional exact
+1-NN sweeps (cloud_pair.py:67-78) with the D2 point-to-plane projection (metric.py:146-153) fused in, the
+np.sum / np.max reductions of the D1 and D2 columns, the cross-rank exchange (N > 1) and the PSNR /
+symmetric aggregation on the host -- i.e. GeoMSE, GeoPSNR and GeoHausdorffDistance for point_to_plane in
+{False, True}, left, right and symmetric, evaluated through the product's own MetricCalculator DAG.  The
+PSNR peak (max extent of A's minimal OBB, CPU/Qhull code in the reference) is injected: it is not part of
+the GPU path.
 
 metric  = Mpoints/s = (N_ref + N_deg) / time per step, whole job over all ranks.
-N > 1   = one process per GPU (torch.distributed, backend nccl = RCCL), query axis sharded with
-          pccm_set_shard; total problem size fixed (BASELINE.json: N_ref = N_deg = 1M at 1/2/4/8
-          GPUs) -> "scaling": "strong".
+N > 1   = one process per GPU (torch.distributed, backend nccl = RCCL), the pair split by direction first and
+          by query rows inside each half (pccm_set_shard_dir); total problem size fixed (BASELINE.json:
+          N_ref = N_deg = 1M at 1/2/4/8 GPUs) -> "scaling": "strong".
+
+Extra records on the same line (N = 1): `full_report` (the step plus the self search behind Min/MaxSqrtDistance,
+which options.py:36-37 always requests), `cold_pair` (a fresh context, nothing inherited), `brute` (the
+brute-force engine north_star names: k1_scan against the fp32 vector roofline), `end_to_end` (fresh pair incl.
+H2D), `cpu_baseline` / `cpu_reference_pattern` and the same-run parity gate against the oracle.
 """
 import argparse
 import gc
@@ -31,6 +37,7 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == f32-MFMA dense peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec peak
 FLOP_PER_PAIR = 8            # 3 sub + 1 mul + 2 fma
+PROFILE_ROUND = "r02"
 
 
 def synth(n):
@@ -59,7 +66,7 @@ def cpu_baseline(a, b, na, nb):
     n = a.shape[0] + b.shape[0]
     return {"value": n / dt / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
             "sample": f"full workload once: {a.shape[0]} vs {b.shape[0]} points, 2 kd-tree builds + 2 sweeps "
-                      f"+ D1/D2 reductions, {dt:.2f} s"}, rep, (hl, hr)
+                      f"+ D1/D2 reductions, {dt:.2f} s"}, rep, (hl, hr), pair
 
 
 def cpu_reference_pattern(a, b, na, nb, sample=20000):
@@ -87,6 +94,20 @@ def cpu_reference_pattern(a, b, na, nb, sample=20000):
             "d2_mse_of_sample": float(mse2)}
 
 
+def committed_traffic(kernel, n, world):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE,
+    separate rocprofv3 --pmc runs over this same command, corrected as MI355X_MICROARCH.md prescribes: a PMC pass
+    cannot run inside this process).  Only quoted for the configuration it was collected on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")) as fh:
+            pmc = json.load(fh).get(kernel, {})
+        if pmc.get("points") == n and world == 1:
+            return pmc["hbm_bytes_per_launch"], f"from the committed profile profiles/{PROFILE_ROUND}/pmc_traffic.json (not measured in this run): " + pmc["note"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, "no PMC profile committed for this engine/size"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +116,9 @@ def main():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--engine", default="auto", choices=["auto", "brute", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip full_report / cold_pair / brute / end_to_end (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--shard-mode", default="direction", choices=["direction", "rows"], help="how N > 1 ranks split the pair")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     args = ap.parse_args()
@@ -112,6 +135,7 @@ def main():
         time.sleep(0.5)
     import torch
     import torch.distributed as dist
+    import open_pcc_metric_amd.metric as m
     from open_pcc_metric_amd import _native as nat
     from open_pcc_metric_amd.calculator import MetricCalculator
     from open_pcc_metric_amd.cloud_pair import CloudPair
@@ -143,18 +167,22 @@ def main():
 
     n = args.points
     a, b, na, nb = synth(n)
-    pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local,
-                     nn_engine=args.engine, group=group, use_graph=not args.no_graph)   # H2D + ingest happen here, untimed
+    pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine,
+                     group=group, use_graph=not args.no_graph, shard_mode=args.shard_mode)   # H2D + ingest happen here, untimed
     eng = pair._engine
     options = CalculateOptions(color=None, hausdorff=False, point_to_plane=True)
     hd_rows = [("GeoHausdorffDistance", True, False), ("GeoHausdorffDistance", False, False)]
 
-    def step():
-        import open_pcc_metric_amd.metric as m
-        pair.recompute()
-        metrics = transform_options(options)[2:]       # drop Min/MaxSqrtDistance: the self search is
-        metrics += [m.GeoHausdorffDistance(True, False), m.GeoHausdorffDistance(False, False)]  # reported apart
-        return MetricCalculator(pair).calculate(metrics).as_dict()
+    def headline_metrics():
+        # Min/MaxSqrtDistance (the self search) are reported apart: `full_report`
+        return transform_options(options)[2:] + [m.GeoHausdorffDistance(True, False), m.GeoHausdorffDistance(False, False)]
+
+    def full_metrics():
+        return transform_options(options) + [m.GeoHausdorffDistance(True, False), m.GeoHausdorffDistance(False, False)]
+
+    def step(p=pair, metrics=headline_metrics):
+        p.recompute()
+        return MetricCalculator(p).calculate(metrics()).as_dict()
 
     def fence():
         if world > 1:
@@ -162,7 +190,21 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 3 if not args.no_graph else 0)):   # eager, capture, first replay
+    def timed(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    nwarm = max(args.warmup, 3 if not args.no_graph else 0)
+    for _ in range(nwarm):   # eager, capture, first replay
         result = step()
     # a full collection of this process (torch, pandas, ... : millions of long-lived objects) is a ~50 ms pause that
     # would land in a random step; park what exists now in the permanent generation.  Nothing of a step is skipped.
@@ -170,12 +212,7 @@ def main():
     gc.freeze()
     eng.profile(args.no_graph)   # HIP events time eager launches; a hipGraph replay cannot carry them (ROCm 7.2)
     eng.profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, result = timed(step, args.steps)
     prof_leg = "HIP events over the timed region"
     if not args.no_graph:
         # kernel durations: the same steps issued eagerly right after the timed region, same process,
@@ -186,26 +223,24 @@ def main():
         for _ in range(min(args.steps, 10)):
             result = step()
         prof_leg = f"HIP events over {min(args.steps, 10)} eager steps issued right after the timed hipGraph region"
+        pair._use_graph = True
     eng.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    prof_steps = args.steps if args.no_graph else min(args.steps, 10)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = (2 * n) / (elapsed / args.steps) / 1e6
 
-    # dominant kernel of this rank, HIP events on the library's stream over the timed region
+    # dominant kernel of this rank, HIP events on the library's stream
     stats = [eng.nn_stats(d) for d in (0, 1)]
     scan_ms, scan_n = eng.profile_get("scan")
     gq_ms, gq_n = eng.profile_get("grid_query")
     prof = {k: eng.profile_get(k) for k in nat.KERNEL_CLASSES}
+    q_rows = sum(eng.shard_range(d)[1] - eng.shard_range(d)[0] for d in (0, 1)) / 2.0     # query rows per direction on this rank
     roofline = None
     if scan_n:
         pairs_per_launch = sum(s["pairs"] for s in stats) / 2.0
         avg_ms = scan_ms / scan_n
         tflops = pairs_per_launch * FLOP_PER_PAIR / (avg_ms * 1e-3) / 1e12
-        q_rows = pairs_per_launch / n
         compulsory = 12.0 * (q_rows + n) + 12.0 * q_rows
         roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / FP32_PEAK_TFLOPS, 4), "traffic": None,
@@ -219,69 +254,121 @@ def main():
                                        "frac": round(compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
     elif gq_n:
         avg_ms = gq_ms / gq_n
-        q_rows = (pair._engine.shard_range(0)[1] - pair._engine.shard_range(0)[0])
         ncells = n / 1.5
-        # one launch serves BOTH directions (pccm_nn_pair).  DESIGN.md section 3, per direction:
-        # query record in + (idx, d2) out = 44 B/query, searched records 32 B/point, cell bounds 4 B/cell
-        alg_bytes = 2.0 * (44.0 * q_rows + 32.0 * n + 4.0 * ncells)
-        # HBM bytes the kernel really moved: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes over this
-        # same command, corrected as MI355X_MICROARCH.md prescribes, committed under profiles/ (a PMC pass cannot run
-        # inside this process); only quoted for the configuration it was collected on
-        traffic, traffic_note = None, "no PMC profile committed for this engine/size"
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh).get("k_grid_query_coop", {})
-            if pmc.get("points") == n and world == 1:
-                traffic = pmc["hbm_bytes_per_launch"]
-                traffic_note = pmc["note"]
-        except (OSError, ValueError, KeyError):
-            pass
+        # one launch serves BOTH directions (pccm_nn_pair).  DESIGN.md section 3, per direction and query:
+        # its 16-byte record in, the row-indexed normal (24 B) in, ONE 32-byte result record (d2, projection, row) out
+        # = 72 B/query; per searched point its 16-byte record once; cell starts of both clouds, 4 B/cell each
+        alg_bytes = 2.0 * (72.0 * q_rows + 16.0 * n + 8.0 * ncells)
+        # SURVEY.md section 8(d)'s layout-independent compulsory bytes: 12 (N_q + N_r) + 24 N_q, + 12 N normals
+        compulsory = 2.0 * (12.0 * (q_rows + n) + 24.0 * q_rows + 12.0 * q_rows)
+        traffic, traffic_note = committed_traffic("k_brick_query", n, world)
         roofline = {"bound": "hbm", "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "kernel": "k_grid_query_coop (ring-1 search of both directions in one launch)",
+                    "frac_compulsory": round(compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "traffic": traffic,
+                    "kernel": "k_brick_query (ring-1 search of both directions + fused D2 projection, one launch)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": gq_n, "algorithmic_bytes_per_launch": alg_bytes,
-                    "traffic_note": traffic_note,
+                    "compulsory_bytes_per_launch": compulsory, "traffic_note": traffic_note,
                     "arithmetic": "fp32 candidate filter in LDS, fp64 decisions and outputs"}
 
     line = {
         "metric": "Mpoints/s for symmetric D1+D2 PSNR, N_ref=N_deg=%s" % (f"{n // 1_000_000}M" if n % 1_000_000 == 0 else n),
         "value": round(value, 4), "unit": "Mpoints/s", "n_gpus": args.gpus, "steps": args.steps,
-        "warmup": args.warmup, "warmup_run": max(args.warmup, 3 if not args.no_graph else 0), "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "warmup": args.warmup, "warmup_run": nwarm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n} vs {n} uniform-random fp32 xyz + unit normals, symmetric D1+D2 MSE/PSNR + D1 Hausdorff "
                                "(BASELINE.json configs[1]+[2])",
-                   "engine": args.engine, "sharding": f"query-axis x{args.gpus}", "hip_graph": not args.no_graph,
+                   "engine": args.engine, "sharding": "none" if world == 1 else f"{args.shard_mode} x{args.gpus}",
+                   "hip_graph": not args.no_graph,
                    "fallback_queries": [s["fallback_queries"] for s in stats],
                    "scan_splits": [s["splits"] for s in stats]},
         "roofline": roofline, "roofline_measured_by": prof_leg,
-        "kernel_ms_total": {k: round(v[0], 3) for k, v in prof.items() if v[1]},
+        "kernel_us_per_step": {k: round(v[0] / prof_steps * 1e3, 1) for k, v in prof.items() if v[1]},
         "result_sample": {"GeoMSE_sym_d1": float(result[("SymmetricMetric", "GeoMSE", True, False, "GeoMSE", False, False)]),
                           "GeoPSNR_sym_d2": float(result[("SymmetricMetric", "GeoPSNR", True, True, "GeoPSNR", False, True)])},
     }
+    if world > 1:
+        # what each rank's GPU spent per step (HIP events): the replicated part of a step is the build of the cloud
+        # a rank searches; everything else shrinks with the rows it owns
+        mine = {"rank": rank, "rows": [list(eng.shard_range(d)) for d in (0, 1)], **line["kernel_us_per_step"]}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        line["per_rank_kernel_us_per_step"] = allr
 
-    if world == 1:
-        # end to end, for the record (never `value`): a FRESH pair per iteration -- upload of both clouds and their normals
-        # from pageable host memory, ingest, both sweeps, the same report -- through the pooled context
+    extras = world == 1 and not args.no_extras
+    if extras:
+        # (1) the full report: the same step plus the self search behind Min/MaxSqrtDistance (options.py:36-37)
+        for _ in range(nwarm):
+            step(metrics=full_metrics)
+        dt, full = timed(lambda: step(metrics=full_metrics), max(10, args.steps // 4))
+        k = max(10, args.steps // 4)
+        line["full_report"] = {"ms_per_step": round(dt / k * 1e3, 4), "value": round(2 * n / (dt / k) / 1e6, 2), "unit": "Mpoints/s",
+                               "steps": k, "note": "step + self search of the origin cloud (third sweep, A vs A) + its min/max "
+                                                   "reduction: every row transform_options() returns, plus the D1 Hausdorff rows"}
+        for _ in range(nwarm):                         # back to the headline report (re-captures its graph)
+            result = step()
+
+        # (2) end to end, for the record (never `value`): a FRESH pair per iteration -- upload of both clouds and their
+        # normals from pageable host memory, ingest, both sweeps, the same report -- through the pooled context
         reps = 5
         t_e2e = 0.0
         for it in range(reps + 1):                   # the first iteration warms the pooled context and is not counted
             if it == 1:
                 t_e2e = time.perf_counter()
             with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine) as fresh:
-                import open_pcc_metric_amd.metric as m
-                metrics = transform_options(options)[2:] + [m.GeoHausdorffDistance(True, False), m.GeoHausdorffDistance(False, False)]
-                MetricCalculator(fresh).calculate(metrics).as_dict()
+                MetricCalculator(fresh).calculate(headline_metrics()).as_dict()
         dt = (time.perf_counter() - t_e2e) / reps
         line["end_to_end"] = {"ms_per_pair": round(dt * 1e3, 4), "value": round(2 * n / dt / 1e6, 2), "unit": "Mpoints/s",
                               "note": "fresh CloudPair per iteration: H2D of 2 clouds + 2 normal sets (pageable), ingest, sweeps, report"}
 
+        # (3) a cold pair: brand-new context (no pooled allocations), nothing inherited from an earlier pair
+        # (PCCM_GRID_NO_REUSE=1: the cell-edge decision with its histogram passes and host round trips runs), one report
+        os.environ["PCCM_GRID_NO_REUSE"] = "1"
+        cold = []
+        for _ in range(3):
+            ce = nat.Engine(local)
+            t0 = time.perf_counter()
+            cp = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], nn_engine=args.engine, _engine=ce)
+            MetricCalculator(cp).calculate(headline_metrics()).as_dict()
+            cold.append(time.perf_counter() - t0)
+            ce.close()
+        del os.environ["PCCM_GRID_NO_REUSE"]
+        line["cold_pair"] = {"ms_per_pair": round(min(cold) * 1e3, 3), "ms_all": [round(c * 1e3, 3) for c in cold],
+                             "note": "new context per pair (hipMalloc of every buffer, stream, events), upload, ingest, grid decisions "
+                                     "taken from scratch, sweeps, report; context teardown not included"}
+
+        # (4) the brute-force engine (the formulation north_star names), a few steps: k1_scan against the fp32 vector peak
+        if args.engine != "brute":
+            with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine="brute") as bp:
+                be = bp._engine
+                step(bp)
+                be.profile(True)
+                be.profile_reset()
+                bsteps = 2
+                t0 = time.perf_counter()
+                for _ in range(bsteps):
+                    bres = step(bp)
+                be.sync()
+                bdt = (time.perf_counter() - t0) / bsteps
+                sms, sn = be.profile_get("scan")
+                be.profile(False)
+                pairs = sum(be.nn_stats(d)["pairs"] for d in (0, 1)) / 2.0
+                tfl = pairs * FLOP_PER_PAIR / (sms / sn * 1e-3) / 1e12 if sn else 0.0
+                line["brute"] = {"ms_per_step": round(bdt * 1e3, 2), "value": round(2 * n / bdt / 1e6, 2), "unit": "Mpoints/s", "steps": bsteps,
+                                 "k1_scan_ms": round(sms / sn, 3) if sn else None, "k1_scan_TFLOPs": round(tfl, 2),
+                                 "k1_scan_frac_of_fp32_vector_peak": round(tfl / FP32_PEAK_TFLOPS, 4),
+                                 "same_rows_as_grid_engine": all(bres[key] == result[key] for key in result)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, rep, hd = cpu_baseline(a, b, na, nb)
+        base, rep, hd, opair = cpu_baseline(a, b, na, nb)
         line["cpu_baseline"] = base
         line["cpu_reference_pattern"] = cpu_reference_pattern(a, b, na, nb)
         # same-run parity gate: every row of the step equals the oracle bit for bit
         bad = [k for k, v in rep.items() if k in result and not (result[k] == v)]
         bad += [k for k, v in zip(hd_rows, hd) if not (result[k] == v)]
+        if extras:
+            mn, mx = opair.min_max_sqrt()
+            bad += [k for k, v in ((("MinSqrtDistance",), mn), (("MaxSqrtDistance",), mx)) if not (full[k] == v)]
         line["parity_vs_oracle"] = "bit-exact" if not bad else f"MISMATCH in {bad}"
     elif rank == 0:
         line["cpu_baseline"] = None

@@ -976,7 +976,10 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         // a second column over the same result records rides along with the job that already reads them
         const double *base = stride == 4 ? (const double *)res->rec.p : dev;
         UnitJob *host_job = nullptr;
-        static const bool merge = [] { const char *e = getenv("PCCM_REDUCE_MERGE"); return !(e && e[0] == '0'); }();
+        static const bool merge = [] {
+            const char *e = getenv("PCCM_REDUCE_MERGE"), *v = getenv("PCCM_REDUCE_VARIANT");
+            return !(e && e[0] == '0') && !(v && atoi(v) == 2);
+        }();
         if (stride == 4 && merge)
             for (int k = 0; k < uj.njobs; ++k)
                 if (uj.j[k].stride == 4 && uj.j[k].val == base && uj.j[k].ncols == 1) host_job = &uj.j[k];
@@ -1032,6 +1035,8 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
     UnitJobs uj;
     pj.njobs = 0; pj.off[0] = 0;
     uj.njobs = 0; uj.uoff[0] = 0; uj.toff[0] = 0;
+    static const int variant = [] { const char *e = getenv("PCCM_REDUCE_VARIANT"); return e ? atoi(e) : 0; }();
+    uj.variant = variant;
     ReduceSlot *fresh[8];
     int nfresh = 0;
     for (int k = 0; k < n; ++k) {

@@ -32,30 +32,49 @@ namespace pccm {
 
 constexpr int kBXMax = 64;
 constexpr int kLcsPitch = kBXMax + 3;                // cell starts per staged run (BX + 2 cells + 1), odd pitch
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float kBigF = 3.0e38f;
+constexpr float kFar = 1.0e18f;                      // coordinates of pad records: d2 ~ 3e36, finite, never the winner
 
 struct BrickParams {
     int bx;                 // cells per brick along x
     int nbx, nby, nbz;      // bricks per axis
     int64_t per_job;        // nbx * nby * nbz
+    uint32_t total;         // bricks of all jobs
     int cap;                // staged records that fit (< 65536: LDS positions are kept as uint16)
+    unsigned long long *stamps;   // diagnostic build only (PCCM_BRICK_STAMP=1): per-phase wave-cycle sums, else null
 };
 
-// NT threads per workgroup, brick of BX x BY x BZ cells.  Occupancy is set by LDS (16 B per staged record), so the
-// kernel spends registers freely: the next query of a lane and its row-indexed normal are in flight while the
-// current one is scanned.
-template <bool SELF, int NT, int BY, int BZ>
-__global__ __launch_bounds__(NT) void k_brick_query(QueryJobs jobs, GridGeom g, BrickParams bp)
+// In-kernel stamps (cdna_hip_programming.md section 7): a SEPARATE instantiation of the kernel, selected by
+// PCCM_BRICK_STAMP=1, adds each wave's cycles per phase into bp.stamps; the product kernel (STAMP = false) executes none.
+#define BRICK_STAMP(k)                                                                       \
+    do {                                                                                     \
+        if (STAMP) {                                                                         \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
+            t_sum[k] += now_ - t_last;        /* registers; flushed once when the wave ends */ \
+            t_last = now_;                                                                   \
+        }                                                                                    \
+    } while (0)
+
+template <bool SELF, int BY, int BZ, bool STAMP, int ABL>   // ABL: timing-only ablations (PCCM_BRICK_ABLATE), wrong results
+__device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom &g, const BrickParams &bp, const uint32_t vblock)
 {
+    if (ABL & 32) return;                                              // timing only: the empty launch
+    const int NT = (int)blockDim.x;
+    unsigned long long t_last = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_sum[6] = {0, 0, 0, 0, 0, 0};
     constexpr int kNRow = BY * BZ;                   // query rows of a brick
     constexpr int kNRun = (BY + 2) * (BZ + 2);       // staged x-runs
     static_assert(kNRun <= 64 && kNRow <= 64, "one wave scans the run / row lengths");
-    extern __shared__ float4 s_rec[];                // [cap + 1]
+    // staged records, two per 32-byte slot, component-interleaved: {x0, x1, y0, y1, z0, z1, row0, row1} -- the scan
+    // reads a slot with two ds_read_b128 and has its packed-fp32 operands (x0 x1), (y0 y1), (z0 z1) in place
+    extern __shared__ float4 s_rec[];                // [cap + 2] records = cap / 2 + 1 slots
     __shared__ uint16_t s_lcs[kNRun * kLcsPitch];
-    __shared__ uint32_t s_g0[kNRun], s_base[kNRun + 1], s_qg0[kNRow], s_qoff[kNRow + 1];
+    __shared__ uint32_t s_g0[kNRun], s_len[kNRun], s_base[kNRun + 1], s_qg0[kNRow], s_qoff[kNRow + 1];
+    float *const s_f = reinterpret_cast<float *>(s_rec);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // XCD-aware order: workgroups b, b+8, ... share an XCD; give every XCD one contiguous eighth of the brick list
-    const uint32_t nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t nblk = bp.total, xcd = vblock & 7u, slot = vblock >> 3;
     const uint32_t bq = nblk >> 3, br = nblk & 7u;
     int64_t vb = (int64_t)(xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + slot;
     const int jb = (jobs.njobs > 1 && vb >= bp.per_job) ? 1 : 0;
@@ -84,14 +103,18 @@ __global__ __launch_bounds__(NT) void k_brick_query(QueryJobs jobs, GridGeom g, 
                 len = cs[rowbase + sx1] - g0;
             }
             s_g0[lane] = g0;
+            s_len[lane] = len;
         }
-        uint32_t inc = len;
+        // every run starts on an even position (a whole slot): odd runs are padded with one far-away record, so the
+        // slot-wise scan below never picks up a record of a neighbouring run twice
+        const uint32_t plen = (len + 1u) & ~1u;
+        uint32_t inc = plen;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(inc, off);
             if (lane >= off) inc += o;
         }
-        if (lane < kNRun) s_base[lane] = inc - len;
+        if (lane < kNRun) s_base[lane] = inc - plen;
         if (lane == kNRun - 1) s_base[kNRun] = inc;
     } else if (w == 1) {
         uint32_t len = 0, q0 = 0;
@@ -114,6 +137,8 @@ __global__ __launch_bounds__(NT) void k_brick_query(QueryJobs jobs, GridGeom g, 
         if (lane == kNRow - 1) s_qoff[kNRow] = inc;
     }
     __syncthreads();
+    BRICK_STAMP(0);                                                    // run bounds + first barrier
+    if (ABL & 16) return;                                              // timing only: bounds + one barrier
     const uint32_t T = s_base[kNRun], NQ = s_qoff[kNRow];
     if (NQ == 0) return;                                               // block-uniform
 
@@ -149,52 +174,94 @@ __global__ __launch_bounds__(NT) void k_brick_query(QueryJobs jobs, GridGeom g, 
     }
 
     // ---- 2. stage cell starts (wave w: runs w, w + NT/64, ...) and records (interleaved 64-record pieces) -------
-    for (int r = w; r < kNRun; r += NT / 64) {
-        const int y = by0 - 1 + r % (BY + 2), z = bz0 - 1 + r / (BY + 2);
-        const bool in = y >= 0 && y < dimy && z >= 0 && z < dimz;      // wave-uniform
-        const uint32_t rowbase = in ? ((uint32_t)z * dimy + y) * dimx : 0u;
-        const uint32_t rebase = s_base[r] - s_g0[r];
-        for (int j = lane; j <= ncs; j += 64)
-            s_lcs[r * kLcsPitch + j] = (uint16_t)(in ? cs[rowbase + sx0 + j] + rebase : s_base[r]);
-    }
-    {
-        int run = 0;                                                   // wave-uniform, monotone
-        for (uint32_t f0 = (uint32_t)w * 64u; f0 < T; f0 += (uint32_t)NT) {
-            while (run + 1 < kNRun && f0 >= s_base[run + 1]) ++run;
-            const uint32_t f = f0 + lane;
-            int myrun = run;
-            while (myrun + 1 < kNRun && f >= s_base[myrun + 1]) ++myrun;
-            if (f < T) s_rec[f] = *reinterpret_cast<const float4 *>(&srecs[s_g0[myrun] + (f - s_base[myrun])]);
-        }
-    }
+    // Every global load of a batch is issued before the first LDS write that depends on one (a copy loop that loads,
+    // waits and writes per record exposes a memory round trip per iteration: the in-kernel stamps put 51 % of the wave
+    // cycles of round 2's first version here).
     const NNOut &out = J.out;
     const bool fuse = out.nrm != nullptr;
     const bool fuse_row = fuse && out.normal_mode == PCCM_NORMAL_ROW;
-    // row-indexed normal (quirk Q1) of the first query: its address is known as soon as the query is here
-    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
-    if (have && fuse_row) {
-        const double *np = out.nrm + 3 * (int64_t)__float_as_int(qn.w);
-        n0 = np[0]; n1 = np[1]; n2 = np[2];
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0;                               // row-indexed normal of the lane's current query
+    {
+        const int nw = NT >> 6;
+        int run = 0;                                                   // wave-uniform, monotone
+        // (the loop bodies run once for every configuration the host picks: <= 4 records per lane, <= 3 runs per wave;
+        // they stay loops for the LDS budgets an override can ask for)
+        for (uint32_t fb = (uint32_t)w * 64u, r0 = (uint32_t)w; fb < T || r0 < (uint32_t)kNRun; fb += 4u * (uint32_t)NT, r0 += 3u * (uint32_t)nw) {
+            // a. record loads
+            float4 rec[4];
+            uint32_t ff[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t f0 = fb + (uint32_t)u * (uint32_t)NT, f = f0 + lane;
+                ff[u] = f;
+                rec[u] = make_float4(kFar, kFar, kFar, __int_as_float(-1));            // the pad of an odd run
+                if (f0 < T) {                                          // wave-uniform
+                    while (run + 1 < kNRun && f0 >= s_base[run + 1]) ++run;
+                    int myrun = run;
+                    while (myrun + 1 < kNRun && f >= s_base[myrun + 1]) ++myrun;
+                    const uint32_t o = f - s_base[myrun];
+                    if (!(ABL & 2) && f < T && o < s_len[myrun]) rec[u] = *reinterpret_cast<const float4 *>(&srecs[s_g0[myrun] + o]);
+                }
+            }
+            // b. cell-start loads of this wave's runs
+            uint32_t v[3][2];
+            bool in[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int r = (int)r0 + u * nw;
+                v[u][0] = v[u][1] = 0u;
+                in[u] = false;
+                if (r < kNRun) {                                       // wave-uniform
+                    const int y = by0 - 1 + r % (BY + 2), z = bz0 - 1 + r / (BY + 2);
+                    in[u] = y >= 0 && y < dimy && z >= 0 && z < dimz;
+                    if (in[u] && !(ABL & 8)) {
+                        const uint32_t *src = cs + ((uint32_t)z * dimy + y) * dimx + sx0;
+                        if (lane <= ncs) v[u][0] = src[lane];
+                        if (lane + 64 <= ncs) v[u][1] = src[lane + 64];
+                    }
+                }
+            }
+            // c. the LDS writes (in the order the loads return)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ff[u] < T) {
+                    float *d = s_f + (ff[u] >> 1) * 8 + (ff[u] & 1u);
+                    d[0] = rec[u].x;
+                    d[2] = rec[u].y;
+                    d[4] = rec[u].z;
+                    d[6] = rec[u].w;
+                }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int r = (int)r0 + u * nw;
+                if (r < kNRun) {
+                    const uint32_t base = s_base[r], rebase = base - s_g0[r];
+                    if (lane <= ncs) s_lcs[r * kLcsPitch + lane] = (uint16_t)(in[u] ? v[u][0] + rebase : base);
+                    if (lane + 64 <= ncs) s_lcs[r * kLcsPitch + lane + 64] = (uint16_t)(in[u] ? v[u][1] + rebase : base);
+                }
+            }
+        }
+        // d. the first query has arrived with the records (loads return in order): its row-indexed normal (quirk Q1)
+        //    travels while the workgroup meets at the barrier and scans
+        __builtin_amdgcn_sched_barrier(0);
+        if (have && fuse_row) {
+            const double *np = out.nrm + 3 * (int64_t)__float_as_int(qn.w);
+            n0 = np[0]; n1 = np[1]; n2 = np[2];
+        }
     }
+    BRICK_STAMP(1);                                                    // staging issued (+ waits of its loads)
     __syncthreads();
+    BRICK_STAMP(2);                                                    // second barrier
 
     // ---- 3. queries ------------------------------------------------------------------------------------------
+    int q_iter = 0;
     while (have) {                                                     // no barrier below: lanes may leave
         const float4 q = qn;
         const int r = rn;
-        const double m0 = n0, m1 = n1, m2 = n2;
         const int qrow = __float_as_int(q.w);
-        // next query of this lane, and its normal: in flight during the scan
+        const double m0 = n0, m1 = n1, m2 = n2;
         const uint32_t qnext = qi + NT;
-        const bool hn = qnext < NQ;
-        if (hn) {
-            rn = query_row(qnext);
-            qn = load_query(qnext, rn);
-            if (fuse_row) {
-                const double *np = out.nrm + 3 * (int64_t)__float_as_int(qn.w);
-                n0 = np[0]; n1 = np[1]; n2 = np[2];
-            }
-        }
+        const bool hn = qnext < NQ;                                    // a leftover query (rare: the workgroup is sized to the brick)
         const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
         const int ly = r % BY, lz = r / BY;
         const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
@@ -202,53 +269,62 @@ __global__ __launch_bounds__(NT) void k_brick_query(QueryJobs jobs, GridGeom g, 
         const int ja = max(cx - 1, 0) - sx0, jb2 = min(cx + 2, dimx) - sx0;
         float best = kBigF, second = kBigF;
         uint32_t bestpos = 0xffffffffu;
+        const v2f qxx = {q.x, q.x}, qyy = {q.y, q.y}, qzz = {q.z, q.z};
+        const uint32_t lds0 = (uint32_t)(uintptr_t)s_rec;
 #pragma unroll
         for (int dz = 0; dz < 3; ++dz) {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
+                // (reading all eighteen run bounds up front, in one LDS round trip, costs nine registers the kernel does
+                // not have below 64 and measured no gain)
                 const int run = (lz + dz) * (BY + 2) + (ly + dy);
                 const uint32_t fs = s_lcs[run * kLcsPitch + ja], fe = s_lcs[run * kLcsPitch + jb2];
-                for (uint32_t f = fs; f < fe; f += 2) {
-                    // two records = 32 contiguous bytes: two ds_read_b128 (4 LDS cycles each).  Left to itself hipcc
-                    // drops the unused row word and issues ds_read_b96, which the LDS serves at 8 cycles per wave
-                    // (MI355X_MICROARCH.md, LDS table): the reads, not the arithmetic, then pace the loop.
-                    float4 c0, c1;                                     // slot f + 1 always exists (cap + 1 slots)
+                // whole slots [fs / 2, ceil(fe / 2)): a slot may bring one record of the neighbouring cell of the same run
+                // (or the run's pad) along -- a real point of the searched cloud farther away than the face the stop rule
+                // tests, so it can only lose; no per-candidate range test is needed
+                // (the loop runs on LDS byte addresses: the position of the best candidate is kept as its address)
+                for (uint32_t a = lds0 + 32u * (fs >> 1), ae = (ABL & 1) ? a + (fs < fe ? 32u : 0u) : lds0 + 32u * ((fe + 1u) >> 1); a < ae; a += 32u) {
+                    // two ds_read_b128 (4 LDS cycles each).  Left to itself hipcc drops the unused row words and issues
+                    // ds_read_b96, which the LDS serves at 8 cycles per wave (MI355X_MICROARCH.md, LDS table)
+                    float4 ca, cb;                                     // (x0 x1 y0 y1), (z0 z1 row0 row1)
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(c0), "=&v"(c1)
-                                 : "v"((uint32_t)(uintptr_t)(&s_rec[f]))
+                                 : "=&v"(ca), "=&v"(cb)
+                                 : "v"(a)
                                  : "memory");
-                    const bool two = f + 1 < fe;
-                    const float ax = q.x - c0.x, ay = q.y - c0.y, az = q.z - c0.z;
-                    const float bx = q.x - c1.x, by = q.y - c1.y, bz = q.z - c1.z;
-                    float d0 = ax * ax, d1 = bx * bx;
-                    d0 = __builtin_fmaf(ay, ay, d0);
-                    d1 = __builtin_fmaf(by, by, d1);
-                    d0 = __builtin_fmaf(az, az, d0);
-                    d1 = __builtin_fmaf(bz, bz, d1);
+                    // both candidates of the slot at once: v_pk_add / v_pk_mul / v_pk_fma_f32
+                    const v2f dx = qxx - v2f{ca.x, ca.y}, dy = qyy - v2f{ca.z, ca.w}, dz = qzz - v2f{cb.x, cb.y};
+                    v2f dd = dx * dx;
+                    dd = __builtin_elementwise_fma(dy, dy, dd);
+                    dd = __builtin_elementwise_fma(dz, dz, dd);
+                    float d0 = dd.x, d1 = dd.y;
                     if (SELF) {
-                        d0 = (__float_as_int(c0.w) == qrow) ? kBigF : d0;
-                        d1 = (__float_as_int(c1.w) == qrow) ? kBigF : d1;
+                        d0 = (__float_as_int(cb.z) == qrow) ? kBigF : d0;
+                        d1 = (__float_as_int(cb.w) == qrow) ? kBigF : d1;
                     }
-                    d1 = two ? d1 : kBigF;
                     second = __builtin_amdgcn_fmed3f(best, second, d0);
                     const bool u0 = d0 < best;
                     best = u0 ? d0 : best;
-                    bestpos = u0 ? f : bestpos;
+                    bestpos = u0 ? a : bestpos;
                     second = __builtin_amdgcn_fmed3f(best, second, d1);
                     const bool u1 = d1 < best;
                     best = u1 ? d1 : best;
-                    bestpos = u1 ? f + 1 : bestpos;
+                    bestpos = u1 ? a + 4u : bestpos;
                 }
             }
         }
-        // certification (bound derived in pccm_brute.hip) + the ring-1 stop rule
-        const double tq = sqrt((double)best) * (1.0 + 0x1.0p-20);
-        const double thr = tq * tq * (1.0 + 0x1.0p-30) + 1.0e-36;
+        BRICK_STAMP(5);                                                // the nine scan loops (incl. query/bounds reads)
+        // certification (bound derived in pccm_brute.hip: every point that can win or tie in fp64 has
+        // d32 <= best (1 + 2^-20)^2 (1 + 2^-30) + 1e-36 for fp32-exact inputs) + the ring-1 stop rule.  In fp32:
+        // best (1 + 2^-18) + 2e-36, rounded once, lies above that bound for every best.
+        const float thr = __builtin_fmaf(best, 1.0f + 0x1.0p-18f, 2.0e-36f);
         bool settled = false;
-        if (bestpos != 0xffffffffu && (double)second > thr) {
-            const float4 c = s_rec[bestpos];
-            const double rx = (double)c.x, ry = (double)c.y, rz = (double)c.z;
-            const int wrow = __float_as_int(c.w);
+        if (ABL & 4) {
+            if (best < 0.0f) out.rec[qrow - out.row_base] = make_double4(0, 0, 0, 0);     // never true: keeps the scan alive
+            settled = true;
+        } else if (bestpos != 0xffffffffu && best < 1.0e30f && second > thr) {          // (a pad record is no neighbour)
+            const float *c = s_f + ((bestpos - lds0) >> 2);         // byte address of the winner's x in its slot
+            const double rx = (double)c[0], ry = (double)c[2], rz = (double)c[4];
+            const int wrow = __float_as_int(c[6]);
             const double d64 = gdist64(qx, qy, qz, rx, ry, rz);
             settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
             if (settled) {
@@ -276,70 +352,164 @@ __global__ __launch_bounds__(NT) void k_brick_query(QueryJobs jobs, GridGeom g, 
             const uint32_t pos = atomicAdd(&J.counters[1], 1u);
             reinterpret_cast<float4 *>(J.tail)[pos] = q;
         }
+        if (hn) {                                                      // fetched only now: keeps the scan's registers free
+            rn = query_row(qnext);
+            qn = load_query(qnext, rn);
+            if (fuse_row) {
+                const double *np = out.nrm + 3 * (int64_t)__float_as_int(qn.w);
+                n0 = np[0]; n1 = np[1]; n2 = np[2];
+            }
+        }
         qi = qnext;
         have = hn;
+        if (STAMP) {
+            BRICK_STAMP(q_iter == 0 ? 3 : 4);                          // first query of the lane / the leftovers
+            ++q_iter;
+        }
+    }
+    if (STAMP && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&bp.stamps[k], t_sum[k]);
+        atomicAdd(&bp.stamps[7], 1ull);                                // waves
     }
 }
 
-// brick shape / workgroup size: PCCM_BRICK="NT,BY,BZ" picks one of the compiled variants (A/B runs)
+// The launch: one workgroup per brick.  (A resident set of workgroups walking the brick list was tried: the loop costs
+// 30 registers -- loop-invariant geometry kept live, SGPRs spilled into VGPRs -- i.e. a workgroup per CU, and the dispatch of
+// 3900 workgroups is not what the kernel waits for: 148 us against 103.)
+// __launch_bounds__(.., 8): 64 VGPRs and <= 80 SGPRs, no spills -- 32 waves (four 512-thread workgroups) resident per CU; the
+// kernel lives on occupancy (two workgroups per CU: 148 us, three: 112 us, four: 104 us at 1M points).  With 81-96 SGPRs
+// the hardware admits one wave per SIMD less than the compiler's occupancy figure says (MI355X_MICROARCH.md, "Residency
+// and cooperative launch").  PCCM_BRICK_V64=0 runs the build without the cap (72 VGPRs, 93 SGPRs) for A/B.
+template <bool SELF, int BY, int BZ, bool STAMP = false, int ABL = 0>
+__global__ __launch_bounds__(1024, 8) void k_brick_query(QueryJobs jobs, GridGeom g, BrickParams bp)
+{
+    brick_body<SELF, BY, BZ, STAMP, ABL>(jobs, g, bp, blockIdx.x);
+}
+
+template <int BY, int BZ>
+__global__ __launch_bounds__(1024) void k_brick_query_free(QueryJobs jobs, GridGeom g, BrickParams bp)
+{
+    brick_body<false, BY, BZ, false, 0>(jobs, g, bp, blockIdx.x);
+}
+
+// brick shape: PCCM_BRICK="BY,BZ[,NT]" picks one of the compiled shapes and optionally forces the workgroup size (A/B runs)
 struct BrickShape {
-    int nt, by, bz;
+    int by, bz, nt;
 };
 
 static BrickShape brick_shape()
 {
     static const BrickShape s = [] {
-        BrickShape v = {512, 4, 2};
+        BrickShape v = {4, 2, 0};
         const char *e = getenv("PCCM_BRICK");
         if (e) {
             int a = 0, b = 0, c = 0;
-            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) v = {a, b, c};
+            const int got = sscanf(e, "%d,%d,%d", &a, &b, &c);
+            if (got >= 2) v = {a, b, got == 3 ? c : 0};
         }
         return v;
     }();
     return s;
 }
 
-template <int NT, int BY, int BZ>
-static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density)
+template <int BY, int BZ>
+static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density_s,
+                         double density_q, int force_nt)
 {
     bp.nby = (g.dim[1] + BY - 1) / BY;
     bp.nbz = (g.dim[2] + BZ - 1) / BZ;
     bp.per_job = (int64_t)bp.nbx * bp.nby * bp.nbz;
     // LDS budget: the expected number of staged records (runs x cells x points per cell) plus a quarter -- occupancy
     // is set by it.  Bricks that hold more (clumped data) hand their queries to the general kernels.
-    const double expect = (double)((BY + 2) * (BZ + 2)) * (bp.bx + 2) * density;
+    const double expect = (double)((BY + 2) * (BZ + 2)) * (bp.bx + 2) * density_s;
     int cap = (int)(1.25 * expect) + 64;
     static const int cap_env = [] { const char *e = getenv("PCCM_BRICK_CAP"); return e ? atoi(e) : 0; }();
     if (cap_env > 0) cap = cap_env;
     if (cap < 256) cap = 256;
     if (cap > 3800) cap = 3800;                         // 60 KB of records: static + dynamic LDS stay under 64 KB
     bp.cap = cap;
-    const size_t lds = (size_t)(bp.cap + 1) * sizeof(float4);
-    dim3 grid((unsigned)(bp.per_job * jobs.njobs));
-    if (self) hipLaunchKernelGGL((k_brick_query<true, NT, BY, BZ>), grid, dim3(NT), lds, ctx->stream, jobs, g, bp);
-    else hipLaunchKernelGGL((k_brick_query<false, NT, BY, BZ>), grid, dim3(NT), lds, ctx->stream, jobs, g, bp);
+    // workgroup size: the queries a brick is expected to hold plus 2.5 sigma (Poisson), in whole waves -- but never
+    // so large that the workgroups the LDS admits per CU exceed the CU's 32 wave slots (occupancy is what hides the
+    // kernel's memory round trips: a few leftover queries per brick cost less than a workgroup per CU)
+    const double eq = (double)(BY * BZ) * bp.bx * density_q;
+    int nt = ((int)(eq + 2.5 * sqrt(eq)) + 63) / 64 * 64;
+    const size_t lds_wg = (size_t)(bp.cap + 2) * sizeof(float4) + (size_t)((BY + 2) * (BZ + 2)) * (kLcsPitch * 2 + 16) + 256;
+    const int wgs_per_cu = (int)((size_t)160 * 1024 / lds_wg) > 0 ? (int)((size_t)160 * 1024 / lds_wg) : 1;
+    const int nt_cap = 64 * (32 / (wgs_per_cu > 16 ? 16 : wgs_per_cu));
+    if (nt > nt_cap) nt = nt_cap;
+    if (force_nt > 0) nt = force_nt / 64 * 64;
+    if (nt < 128) nt = 128;                             // waves 0 and 1 do the bookkeeping of step 1
+    if (nt > 1024) nt = 1024;
+    const size_t lds = (size_t)(bp.cap + 2) * sizeof(float4);
+    bp.total = (uint32_t)(bp.per_job * jobs.njobs);
+    dim3 grid(bp.total);
+    static const bool stamp = [] { const char *e = getenv("PCCM_BRICK_STAMP"); return e && e[0] == '1'; }();
+    bp.stamps = nullptr;
+    if (stamp && !self && !ctx->capturing) {
+        // diagnostic build: phase shares of the wave cycles, printed per launch (never part of a timed or captured run)
+        static unsigned long long *dev = nullptr;
+        if (!dev && hipMalloc((void **)&dev, 8 * sizeof(unsigned long long)) != hipSuccess) dev = nullptr;
+        if (dev) {
+            (void)hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), ctx->stream);
+            bp.stamps = dev;
+            hipLaunchKernelGGL((k_brick_query<false, BY, BZ, true>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+            unsigned long long h[8];
+            (void)hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            const double w = h[7] ? (double)h[7] : 1.0;
+            fprintf(stderr, "[pccm] brick stamps (cycles per wave, %llu waves, nt %d, cap %d): bounds+barrier %.0f | staging %.0f | barrier %.0f | "
+                            "first query: scan %.0f + epilogue %.0f | leftovers %.0f\n",
+                    h[7], nt, bp.cap, h[0] / w, h[1] / w, h[2] / w, h[5] / w, (double)(h[3]) / w, h[4] / w);
+            return;
+        }
+    }
+    static const int ablate = [] { const char *e = getenv("PCCM_BRICK_ABLATE"); return e ? atoi(e) : 0; }();
+    if (ablate && !self && BY == 4 && BZ == 2) {        // timing-only builds: results are wrong by construction
+        if (ablate == 1) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 1>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 2) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 2>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 4) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 4>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 8) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 8>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 7) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 7>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 16) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 16>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 32) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 32>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 15>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        return;
+    }
+    static const bool v_free = [] { const char *e = getenv("PCCM_BRICK_V64"); return e && e[0] == '0'; }();
+    if (v_free && !self) {     // A/B: no register cap
+        hipLaunchKernelGGL((k_brick_query_free<BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        return;
+    }
+    if (self) hipLaunchKernelGGL((k_brick_query<true, BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+    else hipLaunchKernelGGL((k_brick_query<false, BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
 }
 
 int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self)
 {
     BrickParams bp;
-    const int nbx = (g.dim[0] + 47) / 48;                 // bricks of <= 48 cells: ~70 records per staged run at 1.5 points per cell
+    static const int bx_env = [] { const char *e = getenv("PCCM_BRICK_BX"); return e ? atoi(e) : 0; }();
+    const int bx_max = bx_env > 0 ? bx_env : 48;          // bricks of <= 48 cells: ~70 records per staged run at 1.5 points per cell
+    const int nbx = (g.dim[0] + bx_max - 1) / bx_max;
     bp.bx = (g.dim[0] + nbx - 1) / nbx;
     if (bp.bx > kBXMax) bp.bx = kBXMax;
     bp.nbx = (g.dim[0] + bp.bx - 1) / bp.bx;
     bp.nby = bp.nbz = 0;
     bp.per_job = 0;
+    bp.total = 0;
     bp.cap = 0;
+    bp.stamps = nullptr;
     const Grid &gr = ctx->grid;
     const int64_t nmax = gr.n[0] > gr.n[1] ? gr.n[0] : gr.n[1];
     const double density = gr.ncells > 0 ? (double)nmax / (double)gr.ncells : 1.5;      // points per cell of the denser cloud
+    // ... and of the query list (a shard holds a fraction of its cloud's rows)
+    int64_t nqmax = 0;
+    for (int k = 0; k < jobs.njobs; ++k) nqmax = jobs.j[k].nq > nqmax ? jobs.j[k].nq : nqmax;
+    const double density_q = gr.ncells > 0 ? (double)nqmax / (double)gr.ncells : 1.5;
     const BrickShape sh = brick_shape();
-    if (sh.nt == 256 && sh.by == 4 && sh.bz == 2) launch_shape<256, 4, 2>(ctx, jobs, g, self, bp, density);
-    else if (sh.nt == 256 && sh.by == 2 && sh.bz == 2) launch_shape<256, 2, 2>(ctx, jobs, g, self, bp, density);
-    else if (sh.nt == 512 && sh.by == 4 && sh.bz == 4) launch_shape<512, 4, 4>(ctx, jobs, g, self, bp, density);
-    else if (sh.nt == 1024 && sh.by == 4 && sh.bz == 4) launch_shape<1024, 4, 4>(ctx, jobs, g, self, bp, density);
-    else launch_shape<512, 4, 2>(ctx, jobs, g, self, bp, density);
+    if (sh.by == 2 && sh.bz == 2) launch_shape<2, 2>(ctx, jobs, g, self, bp, density, density_q, sh.nt);
+    else if (sh.by == 4 && sh.bz == 4) launch_shape<4, 4>(ctx, jobs, g, self, bp, density, density_q, sh.nt);
+    else launch_shape<4, 2>(ctx, jobs, g, self, bp, density, density_q, sh.nt);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }

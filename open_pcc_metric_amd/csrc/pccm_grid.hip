@@ -68,9 +68,7 @@ __device__ __forceinline__ void consider(const P3 &a, double qx, double qy, doub
 // Scan records [s, e) kBatch at a time: the loads of a batch are independent and issued together
 // (one memory round trip per batch instead of one per record); indices past the end are clamped to
 // e-1, and re-evaluating a record is harmless because the lexicographic min is idempotent.
-constexpr int kBatch = 4;
-
-template <typename REC, bool SELF>
+template <typename REC, bool SELF, int kBatch = 4>
 __device__ __forceinline__ void scan_range(const REC *__restrict__ recs, uint32_t s, uint32_t e, double qx, double qy,
                                            double qz, int qrow, Best &b)
 {
@@ -382,14 +380,17 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
             b.d = INFINITY;
             b.idx = 0x7fffffff;
             bool done = false;
-            for (int r = 1; r <= kMaxRing && !done; ++r) {
+            // every query on the tail list has been through a ring-1 kernel that could not settle it -- mostly because the
+            // stop rule failed, which a second look at ring 1 cannot change: start with the 5 x 5 x 5 cube (it contains
+            // ring 1, scanned here in exact fp64, so uncertified near ties are resolved too)
+            for (int r = 2; r <= kMaxRing && !done; ++r) {
                 const int side = 2 * r + 1;
                 if (lane < side * side) {
                     const int z = cz + lane / side - r, y = cy + lane % side - r;
                     if (z >= 0 && z < dimz && y >= 0 && y < dimy) {
                         const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
                         const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
-                        scan_range<REC, SELF>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
+                        scan_range<REC, SELF, 8>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
                     }
                 }
                 double wm = b.d;
@@ -946,6 +947,8 @@ int grid_prefers_brute(pccm_ctx *ctx, bool *yes)
 static int fused_mode(const pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se)
 {
     if (dir == PCCM_DIR_SELF) return -1;
+    static const bool off = [] { const char *e = getenv("PCCM_NO_FUSE"); return e && e[0] == '1'; }();   // A/B runs
+    if (off) return -1;
     const int mode = ctx->fuse_mode[dir];
     if (mode != PCCM_NORMAL_ROW && mode != PCCM_NORMAL_NEIGHBOUR) return -1;
     if (se.n_nrm <= 0) return -1;

@@ -295,12 +295,25 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
         if (cnt == kLeaf) {
             double v[kLeaf / 8][2];
             // sixteen independent loads first; the layout test sits outside the loop so that they are issued together
-            if (V.stride == 4) {
+            if (V.stride == 4 && jobs.variant == 0) {
 #pragma unroll
                 for (int j = 0; j < kLeaf / 8; ++j) {
                     const double2 t = *reinterpret_cast<const double2 *>(&V.val[(base + 8 * j + k) * 4]);
                     v[j][0] = t.x;
                     v[j][1] = t.y;
+                }
+            } else if (V.stride == 4 && jobs.variant == 1) {      // A/B: the two fields as two 8-byte loads
+#pragma unroll
+                for (int j = 0; j < kLeaf / 8; ++j) {
+                    v[j][0] = V.val[(base + 8 * j + k) * 4];
+                    v[j][1] = V.val[(base + 8 * j + k) * 4 + 1];
+                }
+            } else if (V.stride == 4) {                            // A/B: only the field of column 0 (unmerged jobs)
+#pragma unroll
+                for (int j = 0; j < kLeaf / 8; ++j) {
+                    const double t = V.val[(base + 8 * j + k) * 4 + V.off0];
+                    v[j][0] = V.off0 ? 0.0 : t;
+                    v[j][1] = V.off0 ? t : 0.0;
                 }
             } else {
 #pragma unroll

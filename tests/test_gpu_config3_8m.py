@@ -2,7 +2,7 @@
 
 * one context: every row of the full report equals the oracle's (exact kd-tree, C + OpenMP) bit for bit, and
   size-independent properties hold at full size (fused sums == NumPy's, the returned rows are valid witnesses);
-* query axis sharded over 2 ``gloo`` ranks that share the test box's GPU (the N > 1 path of bench.py --gpus N on the
+* the pair split over 2 ``gloo`` ranks that share the test box's GPU (the N > 1 path of bench.py --gpus N on the
   real kernels): both ranks print the same rows as the single context.
 Needs an MI355X (``-m gpu``) and about two minutes of host time for the oracle at this size."""
 import json
@@ -87,7 +87,7 @@ a, b, na, nb = synth(N)
 pair = CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=0, group=dist.group.WORLD)
 res = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, True))).as_dict()
 with open(os.path.join(os.environ["PCCM_OUT"], f"rank{dist.get_rank()}.json"), "w") as fh:
-    json.dump({"rows": hexrows(res), "shard": list(pair._engine.shard_range(0))}, fh)
+    json.dump({"rows": hexrows(res), "shards": [list(pair._engine.shard_range(d)) for d in (0, 1)]}, fh)
 dist.destroy_process_group()
 '''
 
@@ -106,4 +106,5 @@ def test_config3_8m_two_ranks_match_the_single_context(single, tmp_path):
     ranks = [json.load(open(tmp_path / f"rank{r}.json")) for r in (0, 1)]
     want = hexrows(single["res"])
     assert ranks[0]["rows"] == ranks[1]["rows"] == want
-    assert ranks[0]["shard"][0] == 0 and ranks[0]["shard"][1] == ranks[1]["shard"][0] and ranks[1]["shard"][1] == N
+    # split by direction: rank 0 searches the whole left direction (and builds B's grid only), rank 1 the right one
+    assert ranks[0]["shards"] == [[0, N], [0, 0]] and ranks[1]["shards"] == [[0, 0], [0, N]]

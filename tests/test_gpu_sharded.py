@@ -1,5 +1,5 @@
-"""The N > 1 path on the real kernels: 2 / 3 / 4 / 6 ranks (gloo, sharing the one GPU of the test box -- the box admits
-at most six GPU processes) split the pair by direction and shard the query rows inside each half (or shard rows only:
+"""The N > 1 path on the real kernels: 2 / 3 / 4 ranks (gloo, sharing the one GPU of the test box -- the box admits
+at most six GPU processes at once, the test runner itself being one of them) split the pair by direction and shard the query rows inside each half (or shard rows only:
 shard_mode="rows") and must print the single-process report bit for bit -- geometry, Hausdorff, D2 and the colour rows,
 eager and hipGraph."""
 import json
@@ -83,7 +83,7 @@ def test_two_ranks_on_the_real_kernels_match_one_process(tmp_path, graph, mode):
         assert ranks[1]["shards"][0] == [0, 0] and ranks[1]["shards"][1] == [0, n + 1000]   # rank 1: the right one (+ self)
 
 
-@pytest.mark.parametrize("world", [3, 4, 6])
+@pytest.mark.parametrize("world", [3, 4])
 def test_more_ranks_split_by_direction_then_rows(tmp_path, world):
     n = 100003
     single = _run(tmp_path, 1, "0", "0", n)[0]
