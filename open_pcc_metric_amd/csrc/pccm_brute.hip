@@ -426,7 +426,7 @@ int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Clo
     RescanJobs jobs;
     jobs.njobs = njobs;
     int64_t nqmax = 1;
-    const unsigned cap = 2048;
+    const unsigned cap = 512;     // workgroups: enough to split a cloud finely, few enough that an empty list costs a short launch
     int rc = ensure(ctx, ctx->rescan_part, (size_t)2 * kSplitMax * cap * (sizeof(double) + sizeof(int32_t)));
     if (rc) return rc;
     for (int k = 0; k < njobs; ++k) {

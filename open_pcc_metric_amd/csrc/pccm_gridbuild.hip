@@ -350,6 +350,8 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
     P.ncells = ncells;
     int lg = ceil_log2((ncells + 4095) / 4096);
     P.lg = lg < 10 ? 10 : (lg > kMaxLg ? kMaxLg : lg);
+    static const int lg_env = [] { const char *e = getenv("PCCM_BUILD_LG"); return e ? atoi(e) : 0; }();
+    if (lg_env >= 8 && lg_env <= kMaxLg && (ncells >> lg_env) < 8192) P.lg = lg_env;
     P.nbin = (int)((ncells + (1ll << P.lg) - 1) >> P.lg);
     if (P.nbin > 8192) return fail(PCCM_E_ARG, "grid of %lld cells is too large", (long long)ncells);
     P.ntiles = 0;
@@ -358,7 +360,7 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
         BinJob &d = P.j[k];
         d.x64 = s.x64; d.x32 = s.x32; d.row0 = s.row0; d.cs = s.cs;
         d.n = k < jobs.njobs ? s.n : 0;
-        static const int64_t tile_rows = [] { const char *e = getenv("PCCM_BUILD_TILE"); int64_t v = e ? atoll(e) : 2048; return v >= 256 ? v : 2048; }();
+        static const int64_t tile_rows = [] { const char *e = getenv("PCCM_BUILD_TILE"); int64_t v = e ? atoll(e) : 4096; return v >= 256 ? v : 4096; }();   // 4096 rows per tile: 67 us per build at 1M + 1M points (2048: 71, 1024: 76)
         int64_t nt = (d.n + tile_rows - 1) / tile_rows;
         if (nt > 1024) nt = 1024;
         d.nt = nt;
