@@ -256,9 +256,10 @@ def main():
         avg_ms = gq_ms / gq_n
         ncells = n / 1.5
         # one launch serves BOTH directions (pccm_nn_pair).  DESIGN.md section 3, per direction and query:
-        # its 16-byte record in, the row-indexed normal (24 B) in, ONE 32-byte result record (d2, projection, row) out
-        # = 72 B/query; per searched point its 16-byte record once; cell starts of both clouds, 4 B/cell each
-        alg_bytes = 2.0 * (72.0 * q_rows + 16.0 * n + 8.0 * ncells)
+        # its 16-byte record in, the row-indexed normal (24 B) in, ONE 16-byte result record (d2, projection; the matched
+        # row is left out when nothing will read it: pccm_nn_want_idx) out = 56 B/query; per searched point its 16-byte
+        # record once; cell starts of both clouds, 4 B/cell each
+        alg_bytes = 2.0 * (56.0 * q_rows + 16.0 * n + 8.0 * ncells)
         # SURVEY.md section 8(d)'s layout-independent compulsory bytes: 12 (N_q + N_r) + 24 N_q, + 12 N normals
         compulsory = 2.0 * (12.0 * (q_rows + n) + 24.0 * q_rows + 12.0 * q_rows)
         traffic, traffic_note = committed_traffic("k_brick_query", n, world)

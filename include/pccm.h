@@ -143,6 +143,13 @@ int pccm_nn_pair(pccm_ctx *ctx, int engine);
  * Purely an optimisation: results are bit-identical either way.  Takes effect at the next pccm_nn / pccm_nn_pair. */
 int pccm_nn_fuse(pccm_ctx *ctx, int dir, int normal_mode);
 
+/* Whether the searches keep the matched row of every point (default: on).  Off, a search leaves 16 bytes per point
+ * (squared distance + fused projection) instead of 32 -- half the scattered stores, and columns the reductions read
+ * densely -- which is all that GeoMSE / GeoPSNR / Hausdorff need (metric.py:213-247, 353-386).  Whoever needs the rows
+ * later (pccm_nn_fetch with idx, pccm_error_vectors, the colour calls: cloud_pair.py:34-42, 90-100, 120-124) gets them
+ * anyway: the library repeats the search of that direction with the rows on.  Purely an optimisation. */
+int pccm_nn_want_idx(pccm_ctx *ctx, int on);
+
 /* Copy the shard's results to the host (either pointer may be NULL).  idx[i] is the row in
  * the searched cloud, d2[i] the squared distance: the (idxs, sqrdists) of cloud_pair.py:32-33
  * and the value behind get_left/right_neighbour_distances(), cloud_pair.py:102-106. */

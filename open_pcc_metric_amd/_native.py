@@ -29,7 +29,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
-    "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_fetch",
+    "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_want_idx", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total",
     "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
@@ -94,6 +94,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_nn.argtypes = [vp, i32, i32]
     lib.pccm_nn_pair.argtypes = [vp, i32]
     lib.pccm_nn_fuse.argtypes = [vp, i32, i32]
+    lib.pccm_nn_want_idx.argtypes = [vp, i32]
     lib.pccm_nn_fetch.argtypes = [vp, i32, vp, vp]
     lib.pccm_error_vectors.argtypes = [vp, i32, vp]
     lib.pccm_point_metric.argtypes = [vp, i32, i32, i32, vp]
@@ -408,6 +409,11 @@ class Engine:
     def nn_fuse(self, direction: int, normal_mode: Optional[str]) -> None:
         """Fuse the D2 projection of ``direction`` into the next searches (pccm_nn_fuse); ``None`` switches it off."""
         _check(self._lib.pccm_nn_fuse(self._ctx, int(direction), -1 if normal_mode is None else NORMAL_MODES[normal_mode]))
+
+    def nn_want_idx(self, on: bool) -> None:
+        """Whether the searches store the matched row with every result (pccm_nn_want_idx); off halves the result bytes, and
+        whoever asks for the rows later gets them through a repeated search of that direction."""
+        _check(self._lib.pccm_nn_want_idx(self._ctx, int(bool(on))))
 
     def fetch_nn(self, direction: int, want_idx: bool = True, want_d2: bool = True):
         b, e = self.shard_range(direction)

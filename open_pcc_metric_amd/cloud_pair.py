@@ -312,6 +312,10 @@ class CloudPair:
             return
         for direction, other in ((nat.DIR_LEFT, 1), (nat.DIR_RIGHT, 0)):
             eng.nn_fuse(direction, self.normal_index if self._normals_ready(other) else None)
+        # the matched rows (cloud_pair.py:34-42) are only read by the colour metrics and the error-vector / neighbour
+        # getters: clouds without colours leave them out of the result records (a getter that asks later still gets them)
+        if hasattr(eng, "nn_want_idx"):
+            eng.nn_want_idx(any(_has_colors(c) for c in self.clouds))
 
     def recompute(self) -> None:
         """Run both directional sweeps again on the clouds already resident in HBM
@@ -564,6 +568,14 @@ def _has_normals(cloud) -> bool:
         return bool(has())
     nrm = getattr(cloud, "normals", None)
     return nrm is not None and len(nrm) > 0
+
+
+def _has_colors(cloud) -> bool:
+    has = getattr(cloud, "has_colors", None)
+    if callable(has):
+        return bool(has())
+    col = getattr(cloud, "colors", None)
+    return col is not None and len(col) > 0
 
 
 def _host_rows(a) -> np.ndarray:

@@ -190,7 +190,7 @@ using namespace pccm;
     } while (0)
 
 static void graph_free(GraphRec &g);
-static int ensure_plain(pccm_ctx *ctx, NNResult &res);
+static int ensure_plain(pccm_ctx *ctx, NNResult &res, bool need_idx = true);
 
 #define NOT_CAPTURING(ctx)                                                                          \
     do {                                                                                           \
@@ -690,7 +690,7 @@ static int prepare_nn(pccm_ctx *ctx, int dir, int *trivial)
         if (rc2) return rc2;
     }
     res.rec_valid = false;
-    res.plain_valid = ns <= 0;          // an empty shard has nothing to unpack
+    res.plain_valid = res.plain_d2_valid = ns <= 0;          // an empty shard has nothing to unpack
     res.fused_mode = -1;
     res.stats[0] = res.stats[1] = res.stats[2] = 0;
     *trivial = 0;
@@ -701,7 +701,7 @@ static int prepare_nn(pccm_ctx *ctx, int dir, int *trivial)
             PCCM_HIP(hipMemsetAsync(res.d2, 0, (size_t)ns * sizeof(double), ctx->stream));
         }
         PCCM_HIP(hipMemsetAsync(res.nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
-        res.plain_valid = true;
+        res.plain_valid = res.plain_d2_valid = true;
         *trivial = 1;
     }
     return PCCM_OK;
@@ -740,7 +740,7 @@ static int run_nn(pccm_ctx *ctx, int ndirs, const int *dirs, int engine)
         for (int k = 0; k < ntodo; ++k) {
             const Cloud *it, *se;
             if ((rc = dir_clouds(ctx, todo[k], &it, &se))) return rc;
-            ctx->nn[todo[k]].plain_valid = true;                 // the brute-force engine writes the plain columns
+            ctx->nn[todo[k]].plain_valid = ctx->nn[todo[k]].plain_d2_valid = true;   // the brute-force engine writes the plain columns
             if ((rc = nn_brute(ctx, *it, *se, todo[k] == PCCM_DIR_SELF, ctx->nn[todo[k]]))) return rc;
         }
     }
@@ -773,13 +773,36 @@ static int need_nn(pccm_ctx *ctx, int dir, const Cloud **it, const Cloud **se, N
 
 // the plain idx / d2 columns of a result: the grid engine leaves 32-byte records, unpacked here when somebody
 // wants columns (getters, colour kernels, the separate point kernel)
-static int ensure_plain(pccm_ctx *ctx, NNResult &res)
+static int ensure_plain(pccm_ctx *ctx, NNResult &res, bool need_idx)
 {
-    if (res.plain_valid) return PCCM_OK;
+    if (res.plain_valid || (!need_idx && res.plain_d2_valid)) return PCCM_OK;
     if (!res.rec_valid) return fail(PCCM_E_STATE, "no nearest-neighbour result to read");
-    int rc = launch_unpack(ctx, (const double4 *)res.rec.p, res.end - res.begin, res.idx, res.d2);
+    if (need_idx && res.rec_stride != 4) {
+        // the search ran without the matched rows (pccm_nn_want_idx off) and now somebody asks for them: run it again
+        // for this direction with the rows on -- same results, 32-byte records; the clouds and the grid are resident
+        if (ctx->capturing) {
+            ctx->capture_failed = true;
+            return fail(PCCM_E_STATE, "matched rows are needed during graph capture: switch pccm_nn_want_idx on before the search");
+        }
+        const int dir = (int)(&res - ctx->nn);
+        int rc = nn_grid(ctx, 1, &dir, /*force_idx=*/1);
+        if (rc) return rc;
+    }
+    int rc = launch_unpack(ctx, (const double *)res.rec.p, res.rec_stride, res.end - res.begin, res.idx, res.d2);
     if (rc) return rc;
-    res.plain_valid = true;
+    res.plain_d2_valid = true;
+    res.plain_valid = res.rec_stride == 4;
+    return PCCM_OK;
+}
+
+int pccm_nn_want_idx(pccm_ctx *ctx, int on)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if ((ctx->want_idx != 0) != (on != 0)) {
+        ctx->want_idx = on ? 1 : 0;
+        ctx->epoch++;                                        // captured searches carry the old record layout
+    }
     return PCCM_OK;
 }
 
@@ -805,7 +828,7 @@ int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
     NNResult *res;
     int rc = need_nn(ctx, dir, &it, &se, &res);
     if (rc) return rc;
-    if ((rc = ensure_plain(ctx, *res))) return rc;
+    if ((rc = ensure_plain(ctx, *res, idx != nullptr))) return rc;
     const int64_t ns = res->end - res->begin;
     if (ns > 0 && idx) PCCM_HIP(hipMemcpyAsync(idx, res->idx, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (ns > 0 && d2) PCCM_HIP(hipMemcpyAsync(d2, res->d2, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -860,7 +883,7 @@ static int metric_on_device(pccm_ctx *ctx, int dir, int metric, int normal_mode,
     *ns_out = ns;
     *it_out = it;
     *res_out = res;
-    if ((rc = ensure_plain(ctx, *res))) return rc;
+    if ((rc = ensure_plain(ctx, *res, metric != PCCM_METRIC_D1))) return rc;
     if (metric == PCCM_METRIC_D1) {
         *dev = res->d2;
         return PCCM_OK;
@@ -917,9 +940,9 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     if (metric == PCCM_METRIC_D1) {
         if (res->rec_valid) {
             dev = (const double *)res->rec.p;
-            stride = 4;
+            stride = res->rec_stride;
         } else {
-            if ((rc = ensure_plain(ctx, *res))) return rc;
+            if ((rc = ensure_plain(ctx, *res, false))) return rc;
             dev = res->d2;
         }
     } else {
@@ -928,7 +951,7 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         if ((rc = check_normals(ctx, *it, *se, *res, normal_mode))) return rc;
         if (res->rec_valid && res->fused_mode == normal_mode) {
             dev = (const double *)res->rec.p + 1;
-            stride = 4;
+            stride = res->rec_stride;
             square = metric == PCCM_METRIC_D2 ? 1 : 0;       // metric.py:179: the square of the stored projection
         } else {
             if ((rc = ensure_plain(ctx, *res))) return rc;
@@ -968,21 +991,21 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     if (!s.ev) PCCM_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
     if (s.nunits > 0) {
         UnitCol col;
-        col.off = (stride == 4 && metric != PCCM_METRIC_D1) ? 1 : 0;
+        col.off = (stride >= 2 && metric != PCCM_METRIC_D1) ? 1 : 0;
         col.square = square;
         col.out_units = want_units ? s.host : nullptr;
         col.out_blocks = s.host + 3 * s.nunits;
         col.out_tail = s.host + 3 * s.nunits + 3 * s.nblocks;
         // a second column over the same result records rides along with the job that already reads them
-        const double *base = stride == 4 ? (const double *)res->rec.p : dev;
+        const double *base = stride >= 2 ? (const double *)res->rec.p : dev;
         UnitJob *host_job = nullptr;
         static const bool merge = [] {
             const char *e = getenv("PCCM_REDUCE_MERGE"), *v = getenv("PCCM_REDUCE_VARIANT");
             return !(e && e[0] == '0') && !(v && atoi(v) == 2);
         }();
-        if (stride == 4 && merge)
+        if (stride >= 2 && merge)
             for (int k = 0; k < uj.njobs; ++k)
-                if (uj.j[k].stride == 4 && uj.j[k].val == base && uj.j[k].ncols == 1) host_job = &uj.j[k];
+                if (uj.j[k].stride >= 2 && uj.j[k].val == base && uj.j[k].ncols == 1) host_job = &uj.j[k];
         if (host_job) {
             host_job->c[1] = col;
             host_job->ncols = 2;
@@ -1039,6 +1062,19 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
     uj.variant = variant;
     ReduceSlot *fresh[8];
     int nfresh = 0;
+    // first, whatever may change the layout of a direction's result records: a projection that was not fused into the
+    // search needs the matched rows, and if the search left them out it is repeated (ensure_plain) -- with the rows, and
+    // with the projection fused when the normals have arrived meanwhile.  Only then are the columns of this batch bound to
+    // the records (a job bound earlier would read 16-byte records through a 32-byte stride).
+    for (int k = 0; k < n; ++k) {
+        if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
+        if (metrics[k] == PCCM_METRIC_D1 || dirs[k] == PCCM_DIR_SELF) continue;
+        NNResult &res = ctx->nn[dirs[k]];
+        if (!res.valid || !res.rec_valid || res.fused_mode == normal_modes[k] || res.rec_stride == 4) continue;
+        if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k], want_units)) continue;
+        int rc = ensure_plain(ctx, res, true);
+        if (rc) return rc;
+    }
     for (int k = 0; k < n; ++k) {
         if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
         if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k], want_units)) continue;
@@ -1267,6 +1303,8 @@ static int graph_replay(pccm_ctx *ctx, GraphRec &g)
             ctx->nn[op.dir].rec_valid = op.rec_valid;
             ctx->nn[op.dir].plain_valid = op.plain_valid;
             ctx->nn[op.dir].fused_mode = op.fused_mode;
+            ctx->nn[op.dir].rec_stride = op.rec_stride;
+            ctx->nn[op.dir].plain_d2_valid = op.plain_valid;
         } else if (op.kind == 2) {
             ReduceSlot &s = ctx->slots[op.slot];
             if (s.pending && s.gen == ctx->nn_gen[s.dir]) PCCM_HIP(hipEventSynchronize(s.ev));   // still in use by someone else
@@ -1329,6 +1367,7 @@ int pccm_graph_end(pccm_ctx *ctx, int *graph_id)
             op.rec_valid = ctx->nn[op.dir].rec_valid;
             op.plain_valid = ctx->nn[op.dir].plain_valid;
             op.fused_mode = ctx->nn[op.dir].fused_mode;
+            op.rec_stride = ctx->nn[op.dir].rec_stride;
         }
     g.epoch = ctx->epoch;
     g.valid = true;

@@ -3,29 +3,35 @@
 // Stands under get_neighbour_cloud(), open_pcc_metric/cloud_pair.py:10-42 (one search_knn_vector_3d call per
 // point there), with the D2 projection of metric.py:146-153 fused into the same pass.
 //
-// One workgroup owns a *brick* of the grid: BX x BY x BZ cells (BX <= 64 cells along the x-fastest axis,
+// One workgroup owns a *brick* of the grid: BX x BY x BZ cells (BX <= 48 cells along the x-fastest axis,
 // BY = 4, BZ = 2).  Its queries are the iterating cloud's records in those cells -- eight contiguous runs of
 // the cell-sorted array -- and every candidate any of them can have in ring 1 lies in the (BX+2) x 6 x 4 cells
 // around the brick: 24 contiguous x-runs of the searched cloud's cell-sorted array.
 //   1. 24 + 8 lanes fetch the run bounds (cell_start) of the searched and the iterating cloud; two wave scans
-//      turn them into LDS offsets,
-//   2. the 24 runs are copied into LDS as 16-byte Rec32 records (x, y, z, row: one coalesced global_load_dwordx4
-//      and one ds_write_b128 per record, ~2.4 staged records per query instead of 9.5 per query for the
-//      per-wave staging of round 1) together with their cell starts, rebased to LDS positions,
-//   3. every lane takes queries of the brick in cell-sorted order, so the lanes of a wave sit in neighbouring
-//      cells of one x-row and their LDS reads broadcast or fall on consecutive banks; per query nine
-//      x-runs of three cells each are scanned with one ds_read_b128 per candidate, in fp32, tracking
-//      (best, second best, position of the best),
+//      turn them into LDS offsets (every run starts on an even position: odd runs get one far-away pad record),
+//   2. the 24 runs are copied into LDS -- all global loads of the phase issued before the first LDS write -- two
+//      records per 32-byte slot, component-interleaved {x0 x1 y0 y1 z0 z1 row0 row1} (~3 staged records per query
+//      instead of 9.5 for the per-wave staging of round 1), together with their cell starts, rebased to LDS positions,
+//   3. every lane takes ONE query of the brick (the workgroup is sized to the brick's expected query count) in
+//      cell-sorted order, so the lanes of a wave sit in neighbouring cells of one x-row and their LDS reads broadcast
+//      or fall on consecutive banks; per query nine x-runs of three cells each are scanned slot by slot: two
+//      ds_read_b128, six packed-fp32 instructions for both candidates, (best, second best, address of the best)
+//      tracked per candidate -- 17 VALU instructions per pair.  A slot may bring a record of a neighbouring cell
+//      along: a real point that can only lose, so no per-candidate range test exists,
 //   4. certification as in pccm_brute.hip K2 -- the fp32 winner is the unique fp64 winner when the second best
-//      d32 lies above thr(best) -- then the exact fp64 d2 from the winner's LDS record (fp32-exact inputs:
-//      (double)(float)x == x), the ring-1 stop rule, and the fused epilogue: error vector, projection on the
-//      searched cloud's normal (row i of it: reference quirk Q1, or row nn(i)), ONE 32-byte result record.
-// Queries that are not certified (near ties) or not settled by ring 1 go to the tail list, as before
+//      d32 lies above thr(best), evaluated in fp32 with a conservative margin -- then the exact fp64 d2 from the
+//      winner's LDS record (fp32-exact inputs: (double)(float)x == x), the ring-1 stop rule, and the fused epilogue:
+//      error vector, projection on the searched cloud's normal (row i of it: reference quirk Q1, its gather issued
+//      before the scan; or row nn(i)), ONE 32-byte result record in row order.
+// Queries that are not certified (near ties) or not settled by ring 1 go to the tail list
 // (k_grid_finish -> k2b_fallback).  A brick whose 24 runs do not fit the LDS budget (clumped data) sends all
 // its queries there.
 //
-// Bound: LDS/VALU issue on ~40 candidates per query; HBM sees every record of both clouds about once
-// (neighbouring bricks share runs through the XCD's L2: XCD-aware brick order, as in round 1).
+// Bound: memory latency and the scattered row-order result stores, not arithmetic -- ablations at 1M vs 1M points
+// (PCCM_BRICK_ABLATE, timing-only builds): empty launch 6 us, + run bounds and first barrier 5, + query fetch, pad
+// writes, second barrier and per-query set-up 26, + cell-start loads 10, + record loads and the scan 35, + fp64
+// epilogue, normal gather and result stores 24 = 104 us.  Reported against HBM as the contract asks.
+// Neighbouring bricks share runs through the XCD's L2 (XCD-aware brick order, as in round 1).
 #include "pccm_grid.h"
 
 namespace pccm {
@@ -319,7 +325,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         const float thr = __builtin_fmaf(best, 1.0f + 0x1.0p-18f, 2.0e-36f);
         bool settled = false;
         if (ABL & 4) {
-            if (best < 0.0f) out.rec[qrow - out.row_base] = make_double4(0, 0, 0, 0);     // never true: keeps the scan alive
+            if (best < 0.0f) store_result(out, qrow, 0.0, 0.0, 0);     // never true: keeps the scan alive
             settled = true;
         } else if (bestpos != 0xffffffffu && best < 1.0e30f && second > thr) {          // (a pad record is no neighbour)
             const float *c = s_f + ((bestpos - lds0) >> 2);         // byte address of the winner's x in its slot
@@ -340,12 +346,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
                     p = __fma_rn(ey, e1, p);
                     p = __fma_rn(ez, e2, p);
                 }
-                double4 o;
-                o.x = d64;
-                o.y = p;
-                o.z = __longlong_as_double((long long)(uint32_t)wrow);
-                o.w = 0.0;
-                out.rec[qrow - out.row_base] = o;
+                store_result(out, qrow, d64, p, wrow);
             }
         }
         if (!settled) {

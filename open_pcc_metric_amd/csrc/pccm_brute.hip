@@ -336,12 +336,9 @@ __device__ __forceinline__ void rescan_emit(const RescanJob &J, int64_t i, int b
         p = __fma_rn(ey, J.nrm[3 * k + 1], p);
         p = __fma_rn(ez, J.nrm[3 * k + 2], p);
     }
-    double4 r;
-    r.x = bd;
-    r.y = p;
-    r.z = __longlong_as_double((long long)(uint32_t)bj);
-    r.w = 0.0;
-    J.rec_out[i] = r;
+    double *dst = J.rec_out + i * J.rec_stride;
+    *reinterpret_cast<double2 *>(dst) = make_double2(bd, p);
+    if (J.rec_stride == 4) *reinterpret_cast<double2 *>(dst + 2) = make_double2(__longlong_as_double((long long)(uint32_t)bj), 0.0);
 }
 
 template <bool SELF>
@@ -445,7 +442,8 @@ int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Clo
         J.idx_out = res.idx;
         J.d2_out = res.d2;
         // the grid engine's results are 32-byte records (nn_grid set rec_valid for this run); the brute engine writes columns
-        J.rec_out = res.rec_valid ? (double4 *)res.rec.p : nullptr;
+        J.rec_out = res.rec_valid ? (double *)res.rec.p : nullptr;
+        J.rec_stride = res.rec_stride;
         J.nrm = (res.rec_valid && res.fused_mode >= 0) ? se.nrm64 : nullptr;
         J.normal_mode = res.fused_mode >= 0 ? res.fused_mode : PCCM_NORMAL_ROW;
         J.part_d = (double *)ctx->rescan_part.p + (size_t)k * kSplitMax * cap;

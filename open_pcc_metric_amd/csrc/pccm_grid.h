@@ -110,15 +110,24 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
 int64_t scan_tiles(int64_t m);
 
 // ---- result of one query (all grid kernels and the exact rescan write through this) ---------------------------
-// A settled query leaves ONE 32-byte record in row order: squared distance, signed point-to-plane projection
-// (0 when no normals were attached: pccm_nn_fuse) and the matched row.  One full 32-byte sector per query
-// instead of partial-sector stores into three arrays; the reductions read the records directly.
+// A settled query leaves ONE record in row order: squared distance, signed point-to-plane projection (0 when no
+// normals were attached: pccm_nn_fuse) and -- when somebody will ask for it (pccm_nn_want_idx: getters, colour
+// metrics) -- the matched row: 32 bytes = one full sector, written by two 16-byte stores; without the row 16 bytes, one
+// store, and a column the reductions read densely.  The reductions read the records directly.
 struct NNOut {
-    double4 *rec;          // [rows of the shard], indexed row - row_base
+    double *rec;           // [rows of the shard][stride], indexed row - row_base
+    int stride;            // doubles per record: 4 = {d2, projection, row bits, -}, 2 = {d2, projection}
     const double *nrm;     // normals of the searched cloud, [.][3], or null: projection not fused
     int64_t row_base;
     int normal_mode;       // PCCM_NORMAL_ROW / PCCM_NORMAL_NEIGHBOUR
 };
+
+__device__ __forceinline__ void store_result(const NNOut &o, int qrow, double d2, double p, int wrow)
+{
+    double *dst = o.rec + (int64_t)(qrow - o.row_base) * o.stride;
+    *reinterpret_cast<double2 *>(dst) = make_double2(d2, p);
+    if (o.stride == 4) *reinterpret_cast<double2 *>(dst + 2) = make_double2(__longlong_as_double((long long)(uint32_t)wrow), 0.0);
+}
 
 __device__ __forceinline__ void emit_result(const NNOut &o, int qrow, double qx, double qy, double qz, int wrow, double d2,
                                             double rx, double ry, double rz)
@@ -132,12 +141,7 @@ __device__ __forceinline__ void emit_result(const NNOut &o, int qrow, double qx,
         p = __fma_rn(ey, o.nrm[3 * k + 1], p);
         p = __fma_rn(ez, o.nrm[3 * k + 2], p);
     }
-    double4 r;
-    r.x = d2;
-    r.y = p;
-    r.z = __longlong_as_double((long long)(uint32_t)wrow);
-    r.w = 0.0;
-    o.rec[qrow - o.row_base] = r;
+    store_result(o, qrow, d2, p, wrow);
 }
 
 

@@ -970,7 +970,7 @@ static void launch_queries(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom 
 }
 
 // Exact 1-NN for `ndirs` directions (LEFT and RIGHT fused into the same launches when both are asked for).
-int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
+int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
 {
     int rc;
     // which clouds' search structures this call needs: the searched cloud of every direction with rows here, and the
@@ -1046,13 +1046,15 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs)
         J.row_base = res.begin;
         J.slack32 = exact ? 0.0 : maxabs * 0x1.0p-20;
         const int fm = fused_mode(ctx, dir, it, se);
-        J.out.rec = (double4 *)res.rec.p;
+        res.rec_stride = (ctx->want_idx || force_idx) ? 4 : 2;
+        J.out.rec = (double *)res.rec.p;
+        J.out.stride = res.rec_stride;
         J.out.nrm = fm >= 0 ? se.nrm64 : nullptr;
         J.out.row_base = res.begin;
         J.out.normal_mode = fm >= 0 ? fm : PCCM_NORMAL_ROW;
         res.fused_mode = fm;
         res.rec_valid = true;
-        res.plain_valid = false;
+        res.plain_valid = res.plain_d2_valid = false;
         J.tail = res.tail.p;
         J.counters = res.nflag_dev;                         // [0] full rescans, [1] tail length
         if ((rc = ensure(ctx, res.flagged, (size_t)nq * sizeof(int32_t)))) return rc;

@@ -56,7 +56,9 @@ struct NNResult {
     DevBuf rec;                 // [end-begin] 32-byte result records {d2, projection, row, -} (grid engine; NNOut in pccm_grid.h)
     bool rec_valid = false;     // `rec` holds the last run's results
     bool plain_valid = false;   // idx / d2 hold them
+    bool plain_d2_valid = false;   // d2 alone does (unpacked from records that carry no row)
     int fused_mode = -1;        // normal mode of the projection stored in `rec`, -1: not fused
+    int rec_stride = 4;         // doubles per record: 4 = with the matched row, 2 = {d2, projection} only (pccm_nn_want_idx off)
     int64_t stats[3] = {0, 0, 0};
     uint32_t *nflag_dev = nullptr;  // device counters of the last run: [0] fallback queries, [1] grid tail length
     DevBuf flagged, flag_thr;       // queries handed to the exact rescan (k2b_fallback) and their thresholds
@@ -133,7 +135,7 @@ struct GraphOp {               // host-side effect of one captured call, replaye
     int kind = 0;              // 0 drop_caches, 1 nn(dir), 2 reduce_prefetch(slot)
     int dir = 0, slot = -1;
     bool rec_valid = false, plain_valid = false;   // kind 1: where the direction's results live once the graph has run
-    int fused_mode = -1;
+    int fused_mode = -1, rec_stride = 4;
     ReduceSlot snap;           // kind 2: the slot's bookkeeping at capture time (pointers are not owned)
 };
 
@@ -168,6 +170,7 @@ struct pccm_ctx {
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
     pccm::DevBuf g_bins, g_tmp;            // grid build: per-tile bin histogram + scan state; bin-partitioned records
     bool colsum_configured = false;        // k_color_colsum's dynamic-LDS opt-in was set on this context's device
+    int want_idx = 1;                      // pccm_nn_want_idx: searches store the matched row with every result
     int fuse_mode[3] = {-1, -1, -1};       // pccm_nn_fuse: normal mode of the D2 projection fused into the search, per direction
     pccm::ReduceSlot slots[8];
     uint64_t nn_gen[3] = {1, 1, 1};
@@ -217,7 +220,7 @@ int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, 
 // brute-force engine: fills res.idx / res.d2 for rows [res.begin, res.end) of `it` searched in `se`
 int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResult &res);
 // grid engine
-int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs);
+int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx = 0);   // force_idx: records carry the matched row whatever pccm_nn_want_idx says
 void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
 int grid_ensure(pccm_ctx *ctx, bool need64 = false, int need_mask = 3);   // need64: GridRec records wanted (pccm_normals.hip reads them)
@@ -237,7 +240,8 @@ struct RescanJob {              // flagged queries of one result (k2b_fallback)
     const uint32_t *nflag;      // list length (device)
     int32_t *idx_out;           // plain outputs (brute-force engine) ...
     double *d2_out;
-    double4 *rec_out;           // ... or 32-byte result records with the projection fused (grid engine), when non-null
+    double *rec_out;            // ... or result records with the projection fused (grid engine), when non-null
+    int rec_stride;             // doubles per record (NNResult::rec_stride)
     const double *nrm;          // normals for the fused projection, or null
     int normal_mode;
     double *part_d;             // split regime: [kSplitMax][gridDim.x] partial minima
@@ -269,7 +273,7 @@ struct UnitCol {                // one column reduced from a job's array
     double *out_tail;           // pinned host memory [tail_n]
 };
 struct UnitJob {                // one per-point array to reduce (k_unit_jobs): up to two columns per pass
-    const double *val;          // plain column (stride 1) or the result records (stride 4)
+    const double *val;          // plain column (stride 1) or the result records (stride 2 or 4 doubles)
     int stride;
     int ncols;
     UnitCol c[2];
@@ -285,7 +289,7 @@ struct UnitJobs {
     int64_t toff[9];            // prefix sums of tail_n
 };
 int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs);
-int launch_unpack(pccm_ctx *ctx, const double4 *rec, int64_t ns, int32_t *idx, double *d2);   // result records -> plain columns
+int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int64_t ns, int32_t *idx, double *d2);   // result records -> plain columns
 int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs);
 
 int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,

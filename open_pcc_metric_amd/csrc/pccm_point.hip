@@ -252,8 +252,8 @@ __device__ __forceinline__ UnitView unit_view(const UnitJob &J)
 
 __device__ __forceinline__ void unit_load(const UnitView &J, int64_t i, double v[2])      // the load alone (callers batch them)
 {
-    if (J.stride == 4) {
-        const double2 t = *reinterpret_cast<const double2 *>(&J.val[i * 4]);
+    if (J.stride >= 2) {
+        const double2 t = *reinterpret_cast<const double2 *>(&J.val[i * J.stride]);
         v[0] = t.x;
         v[1] = t.y;
     } else {
@@ -263,7 +263,7 @@ __device__ __forceinline__ void unit_load(const UnitView &J, int64_t i, double v
 
 __device__ __forceinline__ void unit_pick(const UnitView &J, double v[2])                 // fields -> the job's columns
 {
-    if (J.stride == 4) {
+    if (J.stride >= 2) {
         const double x = v[0], y = v[1];
         v[0] = J.off0 ? y : x;
         v[1] = J.off1 ? y : x;
@@ -295,23 +295,23 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
         if (cnt == kLeaf) {
             double v[kLeaf / 8][2];
             // sixteen independent loads first; the layout test sits outside the loop so that they are issued together
-            if (V.stride == 4 && jobs.variant == 0) {
+            if (V.stride >= 2 && jobs.variant == 0) {
 #pragma unroll
                 for (int j = 0; j < kLeaf / 8; ++j) {
-                    const double2 t = *reinterpret_cast<const double2 *>(&V.val[(base + 8 * j + k) * 4]);
+                    const double2 t = *reinterpret_cast<const double2 *>(&V.val[(base + 8 * j + k) * V.stride]);
                     v[j][0] = t.x;
                     v[j][1] = t.y;
                 }
-            } else if (V.stride == 4 && jobs.variant == 1) {      // A/B: the two fields as two 8-byte loads
+            } else if (V.stride >= 2 && jobs.variant == 1) {      // A/B: the two fields as two 8-byte loads
 #pragma unroll
                 for (int j = 0; j < kLeaf / 8; ++j) {
-                    v[j][0] = V.val[(base + 8 * j + k) * 4];
-                    v[j][1] = V.val[(base + 8 * j + k) * 4 + 1];
+                    v[j][0] = V.val[(base + 8 * j + k) * V.stride];
+                    v[j][1] = V.val[(base + 8 * j + k) * V.stride + 1];
                 }
-            } else if (V.stride == 4) {                            // A/B: only the field of column 0 (unmerged jobs)
+            } else if (V.stride >= 2) {                            // A/B: only the field of column 0 (unmerged jobs)
 #pragma unroll
                 for (int j = 0; j < kLeaf / 8; ++j) {
-                    const double t = V.val[(base + 8 * j + k) * 4 + V.off0];
+                    const double t = V.val[(base + 8 * j + k) * V.stride + V.off0];
                     v[j][0] = V.off0 ? 0.0 : t;
                     v[j][1] = V.off0 ? t : 0.0;
                 }
@@ -419,20 +419,20 @@ int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
 }
 
 // Result records -> plain columns (only when a consumer wants them: colour kernels, getters, pccm_nn_fetch).
-__global__ __launch_bounds__(256) void k_unpack(const double4 *__restrict__ rec, int64_t ns, int32_t *__restrict__ idx,
+__global__ __launch_bounds__(256) void k_unpack(const double *__restrict__ rec, int stride, int64_t ns, int32_t *__restrict__ idx,
                                                 double *__restrict__ d2)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ns) return;
-    const double4 r = rec[i];
-    idx[i] = (int32_t)(__double_as_longlong(r.z) & 0xffffffffll);
-    d2[i] = r.x;
+    const double *r = rec + i * stride;
+    if (stride == 4) idx[i] = (int32_t)(__double_as_longlong(r[2]) & 0xffffffffll);      // 16-byte records carry no row
+    d2[i] = r[0];
 }
 
-int launch_unpack(pccm_ctx *ctx, const double4 *rec, int64_t ns, int32_t *idx, double *d2)
+int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int64_t ns, int32_t *idx, double *d2)
 {
     if (ns <= 0) return PCCM_OK;
-    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rec, ns, idx, d2);
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rec, stride, ns, idx, d2);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }

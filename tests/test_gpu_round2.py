@@ -58,6 +58,35 @@ def test_fused_projection_equals_the_separate_pass(engine, mode, n, m):
         assert np.array_equal(fi, idx) and np.array_equal(fd, d2)            # result records unpack to the plain columns
 
 
+def test_results_without_rows_and_rows_on_demand(engine):
+    """pccm_nn_want_idx off: 16-byte result records, identical reductions; the first caller that asks for the matched rows
+    gets them from a repeated search of that direction -- same bits as with the rows on from the start."""
+    rng = np.random.default_rng(21)
+    n, m = 90_000, 80_000
+    a, b = rng.random((n, 3), dtype=np.float32), rng.random((m, 3), dtype=np.float32)
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    engine.set_normals(0, _unit(n, 1)); engine.set_normals(1, _unit(m, 2))
+    for d in (0, 1):
+        engine.nn_fuse(d, "neighbour")
+    engine.nn_want_idx(True)
+    engine.nn_pair("grid")
+    want = {d: (engine.reduce_total(d, nat.METRIC_D1, "neighbour"), engine.reduce_total(d, nat.METRIC_D2, "neighbour"), engine.fetch_nn(d),
+                engine.error_vectors(d)) for d in (0, 1)}
+    engine.nn_want_idx(False)
+    engine.drop_caches(); engine.nn_pair("grid")
+    for d in (0, 1):
+        assert engine.reduce_total(d, nat.METRIC_D1, "neighbour") == want[d][0]
+        assert engine.reduce_total(d, nat.METRIC_D2, "neighbour") == want[d][1]
+        _, d2 = engine.fetch_nn(d, want_idx=False)                  # distances alone: no second search
+        assert np.array_equal(d2, want[d][2][1])
+    for d in (0, 1):
+        idx, d2 = engine.fetch_nn(d)                                # rows on demand
+        assert np.array_equal(idx, want[d][2][0]) and np.array_equal(d2, want[d][2][1])
+        assert np.array_equal(engine.error_vectors(d), want[d][3])
+        assert engine.reduce_total(d, nat.METRIC_D2, "neighbour") == want[d][1]
+    engine.nn_want_idx(True)
+
+
 def test_row_mode_out_of_range_is_not_fused_and_raises(engine):
     rng = np.random.default_rng(3)
     a, b = rng.random((3000, 3), dtype=np.float32), rng.random((2000, 3), dtype=np.float32)
