@@ -185,6 +185,9 @@ int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xve
 int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum);
 /* Unsharded shortcut (world = 1): out = {np.sum, np.min, np.max} of the whole column in one call. */
 int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, double out[3]);
+/* The same for up to 8 columns in one call (out[k][3]): one wait for the GPU and one trip through the FFI per report instead
+ * of one per column -- the np.sum / np.max of every GeoMSE / GeoHausdorffDistance row (metric.py:226-228, 366). */
+int pccm_reduce_total_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, double *out);
 
 /* Colours of cloud `which` ([n][3] RGB in [0, 1] as Open3D holds them; n = the cloud's point count):
  * replaces np.asarray(cloud.colors) behind get_left/right_colors(), cloud_pair.py:114-118. */

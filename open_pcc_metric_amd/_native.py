@@ -31,7 +31,7 @@ SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
     "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_want_idx", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
-    "pccm_reduce_total",
+    "pccm_reduce_total", "pccm_reduce_total_many",
     "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
     "pccm_color_transform", "pccm_lzf_decompress", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
@@ -106,6 +106,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_reduce_prefetch_many.argtypes = [vp, i32, ip, ip, ip]
     lib.pccm_finish_sum.argtypes = [vp, i64, dp]
     lib.pccm_reduce_total.argtypes = [vp, i32, i32, i32, dp]
+    lib.pccm_reduce_total_many.argtypes = [vp, i32, ip, ip, ip, dp]
     lib.pccm_sync.argtypes = [vp]
     lib.pccm_drop_caches.argtypes = [vp]
     lib.pccm_color_transform.argtypes = [vp, i64, i32, vp]
@@ -467,6 +468,15 @@ class Engine:
         out = (ctypes.c_double * 3)()
         _check(self._lib.pccm_reduce_total(self._ctx, int(direction), int(metric), NORMAL_MODES[normal_mode], out))
         return np.float64(out[0]), np.float64(out[1]), np.float64(out[2])
+
+    def reduce_total_many(self, requests, normal_mode: str = "row"):
+        """-> [(sum, min, max)] of up to 8 whole columns ``(direction, metric)`` in one call (unsharded contexts)."""
+        k = len(requests)
+        arr = ctypes.c_int * k
+        out = (ctypes.c_double * (3 * k))()
+        _check(self._lib.pccm_reduce_total_many(self._ctx, k, arr(*[int(r[0]) for r in requests]), arr(*[int(r[1]) for r in requests]),
+                                                arr(*([NORMAL_MODES[normal_mode]] * k)), out))
+        return [(np.float64(out[3 * i]), np.float64(out[3 * i + 1]), np.float64(out[3 * i + 2])) for i in range(k)]
 
     # -- housekeeping -------------------------------------------------------------------------
     def sync(self) -> None:

@@ -133,7 +133,7 @@ class DeviceColumn(_DeviceArray):
         if self._red is None:
             p = self._pair
             if not p._coll.sharded and hasattr(p._engine, "reduce_total"):
-                total, mn, mx = p._engine.reduce_total(self._dir, self._METRIC[self._kind], p.normal_index)
+                total, mn, mx = p._total(self._dir, self._METRIC[self._kind])
             elif p._coll.sharded:
                 total, mn, mx = p._sharded_reduction(self._dir, self._METRIC[self._kind])
             else:
@@ -323,6 +323,7 @@ class CloudPair:
         eng = self._engine
         self._idx_cache = {}
         self._xchg = {}
+        self._totals = {}
         self._colour_red = {}
         if self._use_graph and self._last_wanted is not None and hasattr(eng, "graph_begin"):
             wants_self = "boundary" in self._last_wanted
@@ -403,6 +404,22 @@ class CloudPair:
                                       np.float64(np.max(ext[:, 2 * i])))
                 pos += ln
         return self._xchg[key]
+
+    def _total(self, direction: int, metric: int):
+        """(sum, min, max) of a whole column, unsharded.  The first column a report asks for brings every column the
+        report enqueued (prefetch_reductions) back in ONE call: one wait for the GPU, one trip through ctypes."""
+        key = (direction, metric)
+        if key not in self._totals:
+            eng = self._engine
+            batch = [k for k in self._xchg_wanted if k not in self._totals]
+            if key not in batch:
+                batch.append(key)
+            if hasattr(eng, "reduce_total_many") and len(batch) > 1:
+                for k, v in zip(batch[:8], eng.reduce_total_many(batch[:8], self.normal_index)):
+                    self._totals[k] = v
+            if key not in self._totals:
+                self._totals[key] = eng.reduce_total(direction, metric, self.normal_index)
+        return self._totals[key]
 
     def _neighbour_index(self, direction: int) -> np.ndarray:
         if direction not in self._idx_cache:

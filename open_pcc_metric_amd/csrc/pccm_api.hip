@@ -1172,13 +1172,11 @@ int pccm_finish_sum(const double *xvec, int64_t n_iter, double *sum)
     return PCCM_OK;
 }
 
-int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, double out[3])
+// one column's total from its slot (unsharded): np.sum = chunks of 8192 rows in sequence, each chunk = NumPy's pairwise tree
+// = (tree of its first 32 leaves) + (tree of its last 32 leaves), and the GPU already finished both halves (begin = 0 here)
+static int total_from_slot(pccm_ctx *ctx, int dir, int metric, int normal_mode, double out[3])
 {
-    CHECK_CTX(ctx);
-    NOT_CAPTURING(ctx);
-    if (!out) return fail(PCCM_E_ARG, "null pointer");
     if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
-    if (ctx->sharded()) return fail(PCCM_E_STATE, "pccm_reduce_total needs the whole column on this GPU (world = 1)");
     ReduceSlot *s = slot_find(ctx, dir, metric, normal_mode);
     if (!s) {
         int rc = pccm_reduce_prefetch(ctx, dir, metric, normal_mode);
@@ -1191,8 +1189,6 @@ int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
     const int64_t n = s->n_iter, nunits = s->nunits, nblocks = s->nblocks;
     const int64_t nfull = n / kChunk;
     const double *bsum = s->host + 3 * nunits, *bmin = bsum + nblocks, *bmax = bsum + 2 * nblocks;
-    // np.sum: chunks of 8192 rows in sequence; each chunk = NumPy's pairwise tree = (tree of its first 32
-    // leaves) + (tree of its last 32 leaves), and the GPU already finished both halves (begin = 0 here)
     double total = 0.0;
     bool first = true;
     for (int64_t c = 0; c < nfull; ++c) {
@@ -1212,6 +1208,28 @@ int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
     out[0] = total;
     out[1] = mn;
     out[2] = mx;
+    return PCCM_OK;
+}
+
+int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, double out[3])
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (!out) return fail(PCCM_E_ARG, "null pointer");
+    if (ctx->sharded()) return fail(PCCM_E_STATE, "pccm_reduce_total needs the whole column on this GPU (world = 1)");
+    return total_from_slot(ctx, dir, metric, normal_mode, out);
+}
+
+int pccm_reduce_total_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, double *out)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (n < 0 || n > 8 || (n > 0 && (!dirs || !metrics || !normal_modes || !out))) return fail(PCCM_E_ARG, "1..8 requests expected");
+    if (ctx->sharded()) return fail(PCCM_E_STATE, "pccm_reduce_total_many needs the whole columns on this GPU (world = 1)");
+    int rc = prefetch_many(ctx, n, dirs, metrics, normal_modes, false);       // whatever is not enqueued yet, in one batch
+    if (rc) return rc;
+    for (int k = 0; k < n; ++k)
+        if ((rc = total_from_slot(ctx, dirs[k], metrics[k], normal_modes[k], out + 3 * k))) return rc;
     return PCCM_OK;
 }
 

@@ -104,7 +104,8 @@ struct BuildJobs {
 // Counting sort of the jobs' rows by cell into `recs` (job 0's records, then job 1's); on return every job's
 // cs[c] holds the position of the first record of cell c RELATIVE to the job's first record and cs[ncells] the
 // number of records of the job.
-int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_t ncells, void *recs, bool rec32);
+int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_t ncells, void *recs, bool rec32,
+                 uint32_t *zero = nullptr, int nzero = 0);   // zero: up to 256 words the last kernel clears for the caller
 
 // scratch sizes (so that callers can allocate before a graph capture)
 int64_t scan_tiles(int64_t m);

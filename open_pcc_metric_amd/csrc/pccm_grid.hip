@@ -802,8 +802,9 @@ static bool pair_rec32(const pccm_ctx *ctx)
 
 // (re)build the combined grid when either cloud changed, the caches were dropped or the record layout asked for
 // differs from the built one (need64: a caller that reads GridRec records, pccm_normals.hip)
-static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3)
+static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, uint32_t *zero = nullptr, int nzero = 0, bool *rebuilt = nullptr)
 {
+    if (rebuilt) *rebuilt = false;
     Grid &gr = ctx->grid;
     const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
     const bool rec32 = !need64 && pair_rec32(ctx);
@@ -835,7 +836,8 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3)
         jobs.total += c.n;
     }
     if (jobs.njobs == 1) jobs.j[1] = jobs.j[0];
-    if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, ncells, first, rec32))) return rc;
+    if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, ncells, first, rec32, zero, nzero))) return rc;
+    if (rebuilt) *rebuilt = jobs.total > 0;
     for (int a = 0; a < 3; ++a) {
         gr.dim[a] = g.dim[a];
         gr.org[a] = g.org[a];
@@ -987,7 +989,16 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         for (int d = 0; d < ndirs; ++d) PCCM_HIP(hipMemsetAsync(ctx->nn[dirs[d]].nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
         return PCCM_OK;
     }
-    if ((rc = ensure_grid(ctx, false, need))) return rc;
+    // the directions' counter pairs {rescans, tail length} live side by side: cleared by the last kernel of the grid build
+    // when this call builds the grid (the usual case: the search structure is rebuilt every step), else by one memset
+    int dlo = 2, dhi = 0;
+    for (int d = 0; d < ndirs; ++d) {
+        dlo = dirs[d] < dlo ? dirs[d] : dlo;
+        dhi = dirs[d] > dhi ? dirs[d] : dhi;
+    }
+    const bool side_by_side = ndirs > 0 && dhi - dlo + 1 == ndirs;
+    bool rebuilt = false;
+    if ((rc = ensure_grid(ctx, false, need, side_by_side ? (uint32_t *)ctx->counters.p + 2 * dlo : nullptr, 2 * ndirs, &rebuilt))) return rc;
     const Grid &gr = ctx->grid;
     const GridGeom g = geom_of(gr);
     const uint32_t *cs_all = (const uint32_t *)gr.cell_start.p;
@@ -1000,15 +1011,9 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
     int shard_dirs[3], nshard = 0, job_of_dir[3] = {-1, -1, -1};
     int normal_dirs[2] = {0, 0}, self_dirs[2] = {0, 0};
     int64_t shard_off[3], shard_total = 0;
-    // the directions' counter pairs {rescans, tail length} live side by side: one memset covers this call's
-    int dlo = 2, dhi = 0;
-    for (int d = 0; d < ndirs; ++d) {
-        dlo = dirs[d] < dlo ? dirs[d] : dlo;
-        dhi = dirs[d] > dhi ? dirs[d] : dhi;
-    }
-    if (ndirs > 0 && dhi - dlo + 1 == ndirs)
+    if (side_by_side && !rebuilt)
         PCCM_HIP(hipMemsetAsync((uint32_t *)ctx->counters.p + 2 * dlo, 0, (size_t)2 * ndirs * sizeof(uint32_t), ctx->stream));
-    else
+    else if (!side_by_side)
         for (int d = 0; d < ndirs; ++d)
             PCCM_HIP(hipMemsetAsync(ctx->nn[dirs[d]].nflag_dev, 0, 2 * sizeof(uint32_t), ctx->stream));
     for (int d = 0; d < ndirs; ++d) {

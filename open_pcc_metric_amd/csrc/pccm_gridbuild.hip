@@ -141,6 +141,8 @@ struct BinPlan {
     int64_t hlen;          // nbin * ntiles; hist[hlen] is the scan's sentinel (= total after the scan)
     int64_t state_off;     // uint32 offset of the scan's state words behind the histogram (8-byte aligned)
     int64_t nstate;        // scan tiles + 1 (the ticket)
+    uint32_t *zero;        // words the last build kernel clears for the caller (the searches' counters), or null
+    int nzero;
 };
 
 template <bool X32>
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(256, sizeof(REC) == 16 ? 6 : 4) void k_bin_sort(Bin
         }
     }
     if (b == P.nbin - 1 && tid == 0) J.cs[P.ncells] = e - j0;   // number of records of the job
+    if (blockIdx.x == 0 && tid < P.nzero) P.zero[tid] = 0u;     // saves the caller a memset node
 }
 
 static int ceil_log2(int64_t v)
@@ -343,9 +346,11 @@ static int ceil_log2(int64_t v)
     return l;
 }
 
-int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_t ncells, void *recs, bool rec32)
+int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_t ncells, void *recs, bool rec32, uint32_t *zero, int nzero)
 {
     BinPlan P;
+    P.zero = zero;
+    P.nzero = zero ? nzero : 0;
     P.njobs = jobs.njobs;
     P.ncells = ncells;
     int lg = ceil_log2((ncells + 4095) / 4096);

@@ -5,7 +5,8 @@ R=/root/repo; O=$R/gpurun_out/pmc_coop; mkdir -p $O; cd $R
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVES" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD" \
-           ; do   # NOT the TCP_*_LATENCY / TCC_* sets: that pass aborted inside rocprofv3 (signal 6) and left the run hanging
+           ; do   # the TCP_*_LATENCY / TCC_* counters do not fit one pass ("error code 38: Request exceeds the capabilities of the
+                  # hardware to collect", SIGABRT in rocprofv3): scripts/prof_r02.sh collects them one small set per pass
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-graph > $O/p$i.log 2>&1 || echo "pass $i failed"
 done

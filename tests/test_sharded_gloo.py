@@ -12,6 +12,23 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _torchrun(script, nproc, env, timeout):
+    """Launch `nproc` gloo ranks of `script`; one retry on a fresh port if the rendezvous fails (the probed port can be taken
+    between the probe and torchrun's bind on a busy host)."""
+    import socket
+    proc = None
+    for _ in range(2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        if proc.returncode == 0:
+            break
+    return proc
+
 WORKER = r'''
 import json, os, sys
 import numpy as np
@@ -57,13 +74,7 @@ def test_gloo_ranks_match_single_process(tmp_path, n, world, mode):
     script.write_text(WORKER)
     env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1", PCCM_OUT=str(tmp_path), PCCM_MODE=mode,
                OMP_NUM_THREADS="2")
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    proc = _torchrun(script, world, env, 600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     outs = sorted((json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)), key=lambda o: o["rank"])
     assert [o["rank"] for o in outs] == list(range(world))
@@ -132,13 +143,7 @@ def test_row_indexed_normals_out_of_range_raise_on_every_rank(tmp_path, mode):
     script = tmp_path / "q1_worker.py"
     script.write_text(Q1_WORKER)
     env = dict(os.environ, PCCM_ROOT=ROOT, PCCM_N=str(n), MASTER_ADDR="127.0.0.1", PCCM_OUT=str(tmp_path), PCCM_MODE=mode)
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)       # a hang would trip the timeout
+    proc = _torchrun(script, 2, env, 300)                         # a hang would trip the timeout
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     outs = [json.load(open(tmp_path / f"q1_rank{r}.json")) for r in (0, 1)]
     if mode == "rows":
