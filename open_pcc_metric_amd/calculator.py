@@ -21,10 +21,13 @@ _COLUMNS = ("label", "is_left", "point-to-plane", "value")
 
 
 class CalculateResult:
-    def __init__(self, metrics: typing.List[AbstractMetric]):
+    def __init__(self, metrics: typing.List[AbstractMetric], keys: typing.Optional[typing.List[typing.Tuple]] = None):
         self._metrics = metrics
+        self._keys = keys          # the keys the calculator already derived while planning (same as m._key())
 
     def as_dict(self) -> typing.Dict[typing.Tuple, typing.Any]:
+        if self._keys is not None:
+            return {k: m.value for k, m in zip(self._keys, self._metrics)}
         return {m._key(): m.value for m in self._metrics}
 
     def as_df(self) -> pd.DataFrame:
@@ -67,68 +70,66 @@ class MetricCalculator:
         self._calculated_metrics[key] = metric
         return metric
 
-    def _visit(self, metric, program, planned, wanted):
+    def _visit(self, metric, early, late, planned, wanted):
         """Post-order walk below ``metric`` (a method, not a closure: a recursive closure is a reference cycle that
-        would keep the calculator -- and with it the CloudPair and its GPU context -- alive until the cyclic GC runs)."""
+        would keep the calculator -- and with it the CloudPair and its GPU context -- alive until the cyclic GC runs).
+        Returns (the metric standing for this key, its key, whether it has to wait for the GPU)."""
         key = metric._key()
-        known = self._calculated_metrics.get(key) or planned.get(key)
+        known = self._calculated_metrics.get(key)
+        if known is not None:
+            return known, key, False
+        known = planned.get(key)
         if known is not None:
             return known
         role = getattr(metric, "_pccm_role", 0) or (1 if isinstance(metric, PrimaryMetric) else
                                                     2 if isinstance(metric, SecondaryMetric) else 0)
+        waits = bool(getattr(metric, "_pccm_waits", False))
         if role == 1:
             if isinstance(metric, BoundarySqrtDistances):
                 wanted.append("boundary")
-            program.append((metric, None))
+            (late if waits else early).append((metric, None, key))
         elif role == 2:
             if isinstance(metric, EuclideanDistance):
                 wanted.append((metric.is_left, metric.point_to_plane))
-            resolved = {name: self._visit(dep, program, planned, wanted) for name, dep in metric._get_dependencies().items()}
-            program.append((metric, resolved))
+            resolved = {}
+            for name, dep in metric._get_dependencies().items():
+                resolved[name], _, dep_waits = self._visit(dep, early, late, planned, wanted)
+                waits = waits or dep_waits
+            (late if waits else early).append((metric, resolved, key))
         else:
             raise RuntimeError(f"Metric of unknown AbstractMetric subclass {type(metric).__name__}")
-        planned[key] = metric
-        return metric
+        planned[key] = (metric, key, waits)
+        return planned[key]
 
     def _plan(self, metrics_list: typing.List[AbstractMetric]):
         """Resolve the dependency DAG of the request WITHOUT evaluating anything.
 
-        Returns the evaluation program: ``(metric, resolved dependencies or None)`` in exactly the order
+        Returns the evaluation program: ``(metric, resolved dependencies or None, key)`` in exactly the order
         and with exactly the memoisation of ``_metric_recursive_calculate`` (post-order, first object of a
-        key wins), plus the metric standing for every requested one.  Meanwhile the CloudPair is told
-        which GPU reductions the request contains (``prefetch_reductions``), so they are enqueued -- or, with
-        ``use_graph``, already running -- while this Python bookkeeping happens; the blocking part of a
-        report is then only the ``calculate()`` calls themselves."""
-        program, planned, wanted = [], {}, []
-        requested = [self._visit(m, program, planned, wanted) for m in metrics_list]
+        key wins) -- split into the nodes that only pass device columns along and those that read a reduction
+        back from the GPU or hang off one that does --, plus the metric standing for every requested one.
+        Meanwhile the CloudPair is told which GPU reductions the request contains (``prefetch_reductions``), so
+        they are enqueued -- or, with ``use_graph``, already running -- while this Python bookkeeping happens; the
+        blocking part of a report is then only the late ``calculate()`` calls themselves."""
+        early, late, planned, wanted = [], [], {}, []
+        requested = [self._visit(m, early, late, planned, wanted) for m in metrics_list]
         prefetch = getattr(self._cloud_pair, "prefetch_reductions", None)
         if prefetch is not None and wanted:
             prefetch(sorted(set(wanted), key=str))
-        return program, requested
+        return early, late, [r[0] for r in requested], [r[1] for r in requested]
 
     def calculate(self, metrics_list: typing.List[AbstractMetric]) -> CalculateResult:
-        program, requested = self._plan(metrics_list)
+        early, late, requested, keys = self._plan(metrics_list)
         pair, done = self._cloud_pair, self._calculated_metrics
         # Two passes over the program (calculator.py:85-95, unrolled): first every node that only passes device
         # columns along -- none of them waits for the GPU -- then, in the original order, the reducers and
         # whatever hangs off them.  The first reducer is where the host blocks; nothing is left to do in Python
         # after it that could have been done before.
-        late = []
-        for entry in program:
-            metric, resolved = entry
-            if getattr(metric, "_pccm_waits", False) or (resolved is not None and
-                                                          any(dep._key() not in done for dep in resolved.values())):
-                late.append(entry)
-                continue
-            if resolved is None:
-                metric.calculate(pair)
-            else:
-                metric.calculate(**resolved)
-            done[metric._key()] = metric
-        for metric, resolved in late:
-            if resolved is None:
-                metric.calculate(pair)
-            else:
-                metric.calculate(**resolved)
-            done[metric._key()] = metric
-        return CalculateResult(requested)
+        for program in (early, late):
+            for metric, resolved, key in program:
+                if resolved is None:
+                    metric.calculate(pair)
+                else:
+                    metric.calculate(**resolved)
+                done[key] = metric
+        return CalculateResult(requested, keys)

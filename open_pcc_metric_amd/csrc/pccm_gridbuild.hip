@@ -5,18 +5,24 @@
 //
 // Round 1 ranked every point with one device-scope atomicAdd on its cell counter (78 us for 2M points:
 // scattered agent-scope atomics run ~17x slower than contiguous ones, MI355X_MICROARCH.md "Global float
-// atomics") and scattered 32-byte records from row order.  Here the sort is two-level and every atomic is an
-// LDS atomic:
+// atomics") and scattered 32-byte records from row order.  Here the sort is two-level, three kernels, and the
+// per-point atomics are LDS atomics:
 //   K_A  k_bin_count    one workgroup per tile of rows: LDS histogram over coarse bins (a bin = a run of
-//                       2^lg consecutive cells), written to hist[job][bin][tile]
-//        k_scan_lookback exclusive scan of hist (bin-major): where each tile's share of each bin starts
-//   K_B  k_bin_scatter  same tiles: LDS cursors seeded from the scan, records go to their bin (tmp array)
+//                       2^lg consecutive cells); the tile's share of a bin starts where the bin's running
+//                       total stood -- one returning global atomic per non-empty (tile, bin), 64 consecutive
+//                       words per wave instruction -> toff[tile][bin]
+//   K_B  k_bin_scatter  same tiles: every tile scans the job's bin totals in LDS itself (no scan kernel), adds
+//                       its toff row, and sends the records to their bin (tmp array) through LDS cursors
 //   K_C  k_bin_sort     one workgroup per bin: cell histogram + ranks by LDS atomics, block scan, cell_start
 //                       written coalesced, records written into their cell (registers hold a bin of up to
-//                       kRegRecs records between the two phases; larger bins are streamed twice)
+//                       kRegRecs records between the two phases; larger bins are streamed twice); clears the
+//                       bin's running total for the next build and the searches' counters for the caller
+// (PCCM_BUILD_SCAN=1 keeps round 2's first form for A/B runs: hist[job][bin][tile] + a decoupled look-back
+// scan kernel between K_A and K_B; 3 us slower per build, one more graph node.)
 // Algorithmic bytes per point (Rec32 records): 12 (K_A) + 12 + 16 (K_B) + 16 + 16 (K_C) = 72, plus
 // 4 B per cell for cell_start.  The order of the records inside a cell depends on the arrival order of
-// LDS atomics; no result depends on it (ties are decided by (d2, row) explicitly).
+// LDS atomics, the order of the tiles inside a bin on that of the global ones; no result depends on either
+// (ties are decided by (d2, row) explicitly).
 #include "pccm_grid.h"
 
 namespace pccm {
@@ -129,6 +135,8 @@ struct BinJob {
     int64_t tl;            // rows per tile
     int64_t nt;            // tiles of this job
     int64_t hoff;          // first hist entry of this job (= nbin * tiles of the jobs before it)
+    int64_t base;          // records of the jobs before this one
+    int64_t tile0;         // tiles of the jobs before this one
 };
 
 struct BinPlan {
@@ -143,6 +151,10 @@ struct BinPlan {
     int64_t nstate;        // scan tiles + 1 (the ticket)
     uint32_t *zero;        // words the last build kernel clears for the caller (the searches' counters), or null
     int nzero;
+    // cursor variant (default): no scan kernel.  cursor[job][bin] = running total of the bin (zero on entry; k_bin_sort
+    // leaves it zero again), toff[tile][bin] = where the tile's share starts inside the bin, bstart[job][bin] (+ sentinel)
+    // = first record of the bin, written by the first tile of each job in k_bin_scatter
+    uint32_t *cursor, *toff, *bstart;
 };
 
 template <bool X32>
@@ -172,12 +184,12 @@ __device__ __forceinline__ int tile_job(const BinPlan &P, int64_t &tile)
     return 0;
 }
 
-template <bool X32>
+template <bool X32, bool CUR>
 __global__ __launch_bounds__(256) void k_bin_count(BinPlan P, GridGeom g, uint32_t *__restrict__ hist)
 {
     extern __shared__ uint32_t s_hist[];                  // [nbin]
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0) {                                // the scan's sentinel and state: zero before the scan starts
+    if (!CUR && blockIdx.x == 0) {                                // the scan's sentinel and state: zero before the scan starts
         unsigned long long *state = reinterpret_cast<unsigned long long *>(hist + P.state_off);
         if (tid == 0) hist[P.hlen] = 0u;
         for (int64_t k = tid; k < P.nstate; k += 256) state[k] = 0ull;
@@ -202,20 +214,61 @@ __global__ __launch_bounds__(256) void k_bin_count(BinPlan P, GridGeom g, uint32
             if (i + 256 * k < i1) atomicAdd(&s_hist[bin[k]], 1u);
     }
     __syncthreads();
+    if (CUR) {
+        // the tile's share of every bin starts where the bin's running total stood: one returning atomic per non-empty
+        // (tile, bin), 64 consecutive words per wave instruction; which tile comes first inside a bin is left to chance
+        // (like the order inside a cell: no result depends on it)
+        uint32_t *cur = P.cursor + (int64_t)jb * P.nbin, *dst = P.toff + (J.tile0 + tile) * P.nbin;
+        for (int b = tid; b < P.nbin; b += 256) {
+            const uint32_t c = s_hist[b];
+            dst[b] = c ? atomicAdd(&cur[b], c) : 0u;
+        }
+        return;
+    }
     uint32_t *dst = hist + J.hoff + tile;
     for (int b = tid; b < P.nbin; b += 256) dst[(int64_t)b * J.nt] = s_hist[b];
 }
 
-template <typename REC, bool X32>
+__device__ __forceinline__ void block_scan_inplace(uint32_t *s_cnt, int nc, uint32_t *s_wsum, uint32_t *s_carry);
+
+template <typename REC, bool X32, bool CUR>
 __global__ __launch_bounds__(256) void k_bin_scatter(BinPlan P, GridGeom g, const uint32_t *__restrict__ hist, REC *__restrict__ tmp)
 {
     extern __shared__ uint32_t s_cur[];                   // [nbin]: next free position of each bin's share of this tile
+    __shared__ uint32_t s_wsum[4], s_carry;
     const int tid = threadIdx.x;
     int64_t tile = blockIdx.x;
     const int jb = tile_job(P, tile);
     const BinJob &J = P.j[jb];
-    const uint32_t *src = hist + J.hoff + tile;
-    for (int b = tid; b < P.nbin; b += 256) s_cur[b] = src[(int64_t)b * J.nt];
+    if (CUR) {
+        // every tile scans the job's bin totals itself (nbin <= 8192 words of LDS, a few barriers): no scan kernel
+        const uint32_t *tot = P.cursor + (int64_t)jb * P.nbin, *off = P.toff + (J.tile0 + tile) * P.nbin;
+        uint32_t mine[4];                                 // this thread's first toff words, in flight during the scan
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mine[k] = (tid + 256 * k < P.nbin) ? off[tid + 256 * k] : 0u;
+        for (int b = tid; b < P.nbin; b += 256) s_cur[b] = tot[b];
+        __syncthreads();
+        block_scan_inplace(s_cur, P.nbin, s_wsum, &s_carry);
+        if (tile == 0) {
+            uint32_t *bs = P.bstart + (int64_t)jb * P.nbin;
+            for (int b = tid; b < P.nbin; b += 256) bs[b] = (uint32_t)J.base + s_cur[b];
+        }
+        if (blockIdx.x == 0) {                            // the sentinel, and the bins of a job without rows (it has no tile)
+            const BinJob &L = P.j[P.njobs - 1];
+            if (tid == 0) P.bstart[(int64_t)P.njobs * P.nbin] = (uint32_t)(L.base + L.n);
+            for (int k = 0; k < P.njobs; ++k)
+                if (P.j[k].nt == 0)
+                    for (int b = tid; b < P.nbin; b += 256) P.bstart[(int64_t)k * P.nbin + b] = (uint32_t)P.j[k].base;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < P.nbin) s_cur[tid + 256 * k] += (uint32_t)J.base + mine[k];
+        for (int b = tid + 1024; b < P.nbin; b += 256) s_cur[b] += (uint32_t)J.base + off[b];
+    } else {
+        const uint32_t *src = hist + J.hoff + tile;
+        for (int b = tid; b < P.nbin; b += 256) s_cur[b] = src[(int64_t)b * J.nt];
+    }
     __syncthreads();
     const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
     for (int64_t i = i0 + tid; i < i1; i += 1024) {
@@ -289,9 +342,19 @@ __global__ __launch_bounds__(256, sizeof(REC) == 16 ? 6 : 4) void k_bin_sort(Bin
     const int jb = (P.njobs > 1 && (int)blockIdx.x >= P.nbin) ? 1 : 0;
     const int b = (int)blockIdx.x - jb * P.nbin;
     const BinJob &J = P.j[jb];
-    const uint32_t s = hist[J.hoff + (int64_t)b * J.nt], e = hist[J.hoff + (int64_t)(b + 1) * J.nt];
+    uint32_t s, e, j0;                                    // the bin's records; j0 = first record of this job (cell starts are relative to it)
+    if (P.cursor) {
+        const uint32_t *bs = P.bstart + (int64_t)jb * P.nbin + b;
+        s = bs[0];
+        e = bs[1];
+        j0 = (uint32_t)J.base;
+        if (tid == 0) P.cursor[(int64_t)jb * P.nbin + b] = 0u;   // ready for the next build
+    } else {
+        s = hist[J.hoff + (int64_t)b * J.nt];
+        e = hist[J.hoff + (int64_t)(b + 1) * J.nt];
+        j0 = hist[J.hoff];
+    }
     const uint32_t m = e - s;
-    const uint32_t j0 = hist[J.hoff];                     // first record of this job: cell starts are relative to it
     const int64_t c0 = (int64_t)b << P.lg;
     const int nc = (int)((c0 + (1ll << P.lg) < P.ncells ? c0 + (1ll << P.lg) : P.ncells) - c0);
     for (int c = tid; c < nc; c += 256) s_cnt[c] = 0u;
@@ -372,6 +435,8 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
         d.tl = nt > 0 ? ((d.n + nt - 1) / nt + 255) / 256 * 256 : 256;
         if (nt > 0) d.nt = (d.n + d.tl - 1) / d.tl;       // rounding tl up may leave the last tiles empty: drop them
         d.hoff = (int64_t)P.nbin * P.ntiles;
+        d.tile0 = P.ntiles;
+        d.base = k == 0 ? 0 : P.j[0].n;
         if (k < jobs.njobs) P.ntiles += d.nt;
     }
     P.hlen = (int64_t)P.nbin * P.ntiles;
@@ -379,20 +444,48 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
     P.nstate = st + 1;
     P.state_off = (P.hlen + 2) / 2 * 2;
     const size_t rsz = rec32 ? sizeof(Rec32) : sizeof(GridRec);
-    const size_t hist_bytes = (size_t)P.state_off * sizeof(uint32_t) + (size_t)P.nstate * 8;
+    static const bool use_scan = [] { const char *e = getenv("PCCM_BUILD_SCAN"); return e && e[0] == '1'; }();   // A/B: round-2's first form (hist matrix + look-back scan)
+    const bool cur = !use_scan && P.nbin <= 8192;
+    const int64_t ncur = (int64_t)P.njobs * P.nbin;
+    const size_t cur_words = (size_t)(2 * 8192 + 2 * 8192 + 2);          // cursor | bstart (+ sentinel), fixed places
+    const size_t hist_bytes = cur ? (cur_words + (size_t)P.hlen) * sizeof(uint32_t)
+                                  : (size_t)P.state_off * sizeof(uint32_t) + (size_t)P.nstate * 8;
     int rc;
-    if ((rc = ensure(ctx, ctx->g_bins, hist_bytes))) return rc;
+    const size_t bins_before = ctx->g_bins.bytes;        // ensure() only ever grows a buffer
+    if ((rc = ensure(ctx, ctx->g_bins, hist_bytes > cur_words * sizeof(uint32_t) ? hist_bytes : cur_words * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->g_tmp, (size_t)(jobs.total > 0 ? jobs.total : 1) * rsz))) return rc;
     uint32_t *hist = (uint32_t *)ctx->g_bins.p;
+    P.cursor = P.toff = P.bstart = nullptr;
+    if (cur) {
+        P.cursor = hist;
+        P.bstart = hist + 2 * 8192;
+        P.toff = hist + cur_words;
+        if (ctx->g_bins.bytes != bins_before || !ctx->bins_clean) {           // new memory, or a build that did not finish: cursors to zero
+            if (ctx->capturing) {
+                ctx->capture_failed = true;
+                return fail(PCCM_E_STATE, "the grid build's scratch must exist before graph capture: run the sequence once first");
+            }
+            PCCM_HIP(hipMemsetAsync(hist, 0, (size_t)2 * 8192 * sizeof(uint32_t), ctx->stream));
+        }
+        ctx->bins_clean = false;
+    }
     unsigned long long *state = reinterpret_cast<unsigned long long *>(hist + P.state_off);
     const size_t lds_bins = (size_t)P.nbin * sizeof(uint32_t), lds_cells = ((size_t)1 << P.lg) * sizeof(uint32_t);
-    if (P.ntiles > 0) {
+    if (P.ntiles > 0 && cur) {
         dim3 tg((unsigned)P.ntiles);
-        if (rec32) hipLaunchKernelGGL((k_bin_count<true>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
-        else hipLaunchKernelGGL((k_bin_count<false>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
+        if (rec32) hipLaunchKernelGGL((k_bin_count<true, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
+        else hipLaunchKernelGGL((k_bin_count<false, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
+        if (rec32) hipLaunchKernelGGL((k_bin_scatter<Rec32, true, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (Rec32 *)ctx->g_tmp.p);
+        else hipLaunchKernelGGL((k_bin_scatter<GridRec, false, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (GridRec *)ctx->g_tmp.p);
+    } else if (P.ntiles > 0) {
+        dim3 tg((unsigned)P.ntiles);
+        if (rec32) hipLaunchKernelGGL((k_bin_count<true, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
+        else hipLaunchKernelGGL((k_bin_count<false, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
         hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)st), dim3(256), 0, ctx->stream, hist, P.hlen + 1, state, st);
-        if (rec32) hipLaunchKernelGGL((k_bin_scatter<Rec32, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (Rec32 *)ctx->g_tmp.p);
-        else hipLaunchKernelGGL((k_bin_scatter<GridRec, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (GridRec *)ctx->g_tmp.p);
+        if (rec32) hipLaunchKernelGGL((k_bin_scatter<Rec32, true, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (Rec32 *)ctx->g_tmp.p);
+        else hipLaunchKernelGGL((k_bin_scatter<GridRec, false, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (GridRec *)ctx->g_tmp.p);
+    } else if (cur) {
+        PCCM_HIP(hipMemsetAsync(P.bstart, 0, (size_t)(ncur + 1) * sizeof(uint32_t), ctx->stream));
     } else {
         PCCM_HIP(hipMemsetAsync(hist, 0, hist_bytes, ctx->stream));
     }
@@ -400,6 +493,7 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
     if (rec32) hipLaunchKernelGGL((k_bin_sort<Rec32>), bg, dim3(256), lds_cells, ctx->stream, P, g, (const uint32_t *)hist, (const Rec32 *)ctx->g_tmp.p, (Rec32 *)recs);
     else hipLaunchKernelGGL((k_bin_sort<GridRec>), bg, dim3(256), lds_cells, ctx->stream, P, g, (const uint32_t *)hist, (const GridRec *)ctx->g_tmp.p, (GridRec *)recs);
     PCCM_HIP(hipGetLastError());
+    ctx->bins_clean = true;                                // k_bin_sort has been queued: it leaves the cursors at zero
     return PCCM_OK;
 }
 

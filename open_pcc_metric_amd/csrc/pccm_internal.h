@@ -169,6 +169,7 @@ struct pccm_ctx {
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
     pccm::DevBuf g_bins, g_tmp;            // grid build: per-tile bin histogram + scan state; bin-partitioned records
+    bool bins_clean = false;   // the build's bin cursors (head of g_bins) are zero on the stream
     bool colsum_configured = false;        // k_color_colsum's dynamic-LDS opt-in was set on this context's device
     int want_idx = 1;                      // pccm_nn_want_idx: searches store the matched row with every result
     int fuse_mode[3] = {-1, -1, -1};       // pccm_nn_fuse: normal mode of the D2 projection fused into the search, per direction

@@ -198,13 +198,26 @@ class GeoMSE(_OverEuclidean):                                    # metric.py:213
     _pccm_waits = True      # reads a reduction back from the GPU: the calculator evaluates these last
     def calculate(self, euclidean_distance: EuclideanDistance) -> None:
         column = euclidean_distance.value
-        self.value = np.sum(column, axis=0) / column.shape[0]
+        fused = getattr(column, "_reduced", None)             # a device column: what np.sum would dispatch to, called directly
+        total = fused()[0] if fused is not None else None
+        self.value = (np.sum(column, axis=0) if total is None else total) / column.shape[0]
 
 
 class GeoHausdorffDistance(_OverEuclidean):                      # metric.py:353-366 (a SQUARED distance)
     _pccm_waits = True      # reads a reduction back from the GPU: the calculator evaluates these last
     def calculate(self, euclidean_distance: EuclideanDistance) -> None:
-        self.value = np.max(euclidean_distance.value, axis=0)
+        column = euclidean_distance.value
+        fused = getattr(column, "_reduced", None)             # a device column: what np.max would dispatch to, called directly
+        self.value = fused()[2] if fused is not None else np.max(column, axis=0)
+
+
+def _peak_of(cloud_extent):
+    """np.max(cloud_extent.value), evaluated once per extent array (a report asks for it four times)."""
+    extent = cloud_extent.value
+    memo = cloud_extent.__dict__.get("_peak_memo")
+    if memo is None or memo[0] is not extent:
+        memo = cloud_extent._peak_memo = (extent, np.max(extent))
+    return memo[1]
 
 
 def _psnr(peak, distortion):
@@ -217,7 +230,7 @@ class GeoPSNR(SecondaryMetric, PointToPlaneable):                # metric.py:231
                 "geo_mse": GeoMSE(is_left=self.is_left, point_to_plane=self.point_to_plane)}
 
     def calculate(self, cloud_extent: CloudExtent, geo_mse: GeoMSE) -> None:
-        self.value = _psnr(np.max(cloud_extent.value), geo_mse.value)
+        self.value = _psnr(_peak_of(cloud_extent), geo_mse.value)
 
 
 class GeoHausdorffDistancePSNR(SecondaryMetric, PointToPlaneable):   # metric.py:369-386

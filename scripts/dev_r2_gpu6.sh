@@ -1,12 +1,28 @@
 #!/bin/bash
+# round-2 dev: scan-free grid build (bin cursors) vs the look-back scan; reduction results to device vs pinned host memory
 set -o pipefail
-mkdir -p gpurun_out/r2f
 cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r2f; mkdir -p $O
 export TMPDIR=/tmp
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r2f/smoke.log 2>&1 || { echo SMOKE FAILED; tail -20 gpurun_out/r2f/smoke.log; exit 1; }
-tail -1 gpurun_out/r2f/smoke.log
-for v in 4,2,512 4,2,576 2,2,256 4,2,256; do
-  PCCM_BRICK=$v PCCM_BRICK_STAMP=1 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-extras > gpurun_out/r2f/stamp_$v.json 2> gpurun_out/r2f/stamp_$v.err
-  echo "variant $v"; grep "brick stamps" gpurun_out/r2f/stamp_$v.err | tail -2
-done
-timeout -k 10 300 python scripts/dev_host_profile.py > gpurun_out/r2f/host.log 2>&1; head -30 gpurun_out/r2f/host.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { echo SMOKE FAILED; tail -20 $O/smoke.log; exit 1; }
+tail -1 $O/smoke.log
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_round2.py -x -q > $O/parity.log 2>&1; rc=$?; echo "parity rc=$rc $(tail -1 $O/parity.log)"
+[ $rc -eq 0 ] || { tail -40 $O/parity.log; exit 1; }
+run() {  # name, mode flags, env...
+  name=$1; shift; flags=$1; shift
+  env "$@" timeout -k 10 300 python bench.py --steps 100 $flags --no-extras --no-cpu-baseline > $O/bench_$name.json 2> $O/bench_$name.err || { echo "$name FAILED"; tail -5 $O/bench_$name.err; return; }
+  python - <<PY
+import json
+d=json.load(open("$O/bench_$name.json"))
+print("$name ms/step", d["ms_per_step"], d.get("kernel_us_per_step"), d.get("parity"))
+PY
+}
+run eager_default --no-graph X=1
+run eager_scan --no-graph PCCM_BUILD_SCAN=1
+run eager_devout --no-graph PCCM_REDUCE_DEVOUT=1
+run graph_default "" X=1
+run graph_scan "" PCCM_BUILD_SCAN=1
+run graph_devout "" PCCM_REDUCE_DEVOUT=1
+run graph_default2 "" X=1
+timeout -k 10 300 python scripts/host_split.py --points 1000000 2>&1 | tail -2
+timeout -k 10 300 python scripts/host_split.py --points 4096 --steps 1000 2>&1 | tail -2
