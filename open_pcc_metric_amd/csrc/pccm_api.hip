@@ -113,12 +113,14 @@ static void free_cloud(Cloud &c)
     if (c.xyz32) (void)hipFree(c.xyz32);
     if (c.xyz64) (void)hipFree(c.xyz64);
     if (c.nrm64) (void)hipFree(c.nrm64);
+    if (c.nrm32) (void)hipFree(c.nrm32);
     if (c.rgb64) (void)hipFree(c.rgb64);
     c.xyz32 = nullptr;
     c.xyz64 = nullptr;
     c.nrm64 = nullptr;
+    c.nrm32 = nullptr;
     c.rgb64 = nullptr;
-    c.cap32 = c.cap64 = c.cap_nrm = c.cap_rgb = 0;
+    c.cap32 = c.cap64 = c.cap_nrm = c.cap_nrm32 = c.cap_rgb = 0;
     c.n = c.n_pad = c.n_nrm = c.n_rgb = 0;
 }
 
@@ -349,15 +351,17 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
     for (int d = 0; d < 3; ++d) ctx->nn_gen[d]++;      // pending D2 reductions used the old normals
     ctx->epoch++;
     c.n_nrm = 0;
+    c.nrm_exact32 = false;
     int rc = grow((void **)&c.nrm64, c.cap_nrm, (size_t)n * 3 * sizeof(double));
     if (rc) return rc;
+    if ((rc = grow((void **)&c.nrm32, c.cap_nrm32, (size_t)n * sizeof(float4)))) return rc;
     const size_t esz = dtype == PCCM_F32 ? 4 : 8;
     const void *dsrc = nullptr;
     rc = upload(ctx, nrm, (size_t)n * 3 * esz, on_device, &dsrc);
     if (rc) return rc;
     unsigned long long *stats = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
-    rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.nrm64, stats);
+    rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.nrm64, (float *)c.nrm32, stats);
     if (rc) return rc;
     unsigned long long h[3];
     PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -366,6 +370,7 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
         return fail(PCCM_E_ARG, "normals of cloud %d are not finite", which);      // n_nrm stays 0: no normals
     }
     c.n_nrm = n;
+    c.nrm_exact32 = h[1] == 0;      // the search's fused projection then gathers 16 bytes per normal instead of 24 unaligned ones
     return PCCM_OK;
 }
 
@@ -388,7 +393,7 @@ int pccm_set_colors(pccm_ctx *ctx, int which, const void *rgb, int64_t n, int dt
     if (rc) return rc;
     unsigned long long *stats = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
-    rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.rgb64, stats);      // same widening copy; non-finite values are
+    rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.rgb64, nullptr, stats);      // same widening copy; non-finite values are
     if (rc) return rc;                                                    // allowed here (NumPy propagates them)
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     c.n_rgb = n;

@@ -40,6 +40,7 @@ constexpr int kBXMax = 64;
 constexpr int kLcsPitch = kBXMax + 3;                // cell starts per staged run (BX + 2 cells + 1), odd pitch
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float kBigF = 3.0e38f;
+constexpr int kExtra = 21;                           // lanes per run of the staging's second load (3 x 21 <= 64)
 constexpr float kFar = 1.0e18f;                      // coordinates of pad records: d2 ~ 3e36, finite, never the winner
 
 struct BrickParams {
@@ -61,6 +62,18 @@ struct BrickParams {
             t_last = now_;                                                                   \
         }                                                                                    \
     } while (0)
+
+// the normal of `row`: one aligned 16-byte word when the cloud's normals are fp32-exact (exact widening), else 24 bytes of fp64
+__device__ __forceinline__ void load_normal(const NNOut &o, int row, double &a, double &b, double &c)
+{
+    if (o.nrm32) {
+        const float4 t = o.nrm32[row];
+        a = (double)t.x; b = (double)t.y; c = (double)t.z;
+    } else {
+        const double *np = o.nrm + 3 * (int64_t)row;
+        a = np[0]; b = np[1]; c = np[2];
+    }
+}
 
 template <bool SELF, int BY, int BZ, bool STAMP, int ABL>   // ABL: timing-only ablations (PCCM_BRICK_ABLATE), wrong results
 __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom &g, const BrickParams &bp, const uint32_t vblock)
@@ -189,32 +202,41 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
     double n0 = 0.0, n1 = 0.0, n2 = 0.0;                               // row-indexed normal of the lane's current query
     {
         const int nw = NT >> 6;
-        int run = 0;                                                   // wave-uniform, monotone
-        // (the loop bodies run once for every configuration the host picks: <= 4 records per lane, <= 3 runs per wave;
-        // they stay loops for the LDS budgets an override can ask for)
-        for (uint32_t fb = (uint32_t)w * 64u, r0 = (uint32_t)w; fb < T || r0 < (uint32_t)kNRun; fb += 4u * (uint32_t)NT, r0 += 3u * (uint32_t)nw) {
-            // a. record loads
-            float4 rec[4];
-            uint32_t ff[4];
+        // Wave w copies runs w, w + nw, w + 2 nw (a run = the records of BX + 2 consecutive cells, contiguous in the
+        // cell-sorted array: lane l takes record l and l + 64 of it -- no search for "which run is position f in", which
+        // cost the flat 64-record pieces of the first version a chain of dependent LDS reads per load).
+        // (the loop body runs once for every configuration the host picks: 24 runs, 8 waves)
+        for (int r0 = w; r0 < kNRun; r0 += 3 * nw) {
+            // a. record loads: records 0..63 of each of the three runs, and ONE more load for what the runs have beyond
+            //    (a run holds ~69 records here: lanes 0..20 take records 64..84 of the first run, 21..41 of the second,
+            //    42..62 of the third; longer runs finish in the loop below)
+            float4 rec[3], rex;
+            uint32_t rb[3], rl[3], rg[3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t f0 = fb + (uint32_t)u * (uint32_t)NT, f = f0 + lane;
-                ff[u] = f;
-                rec[u] = make_float4(kFar, kFar, kFar, __int_as_float(-1));            // the pad of an odd run
-                if (f0 < T) {                                          // wave-uniform
-                    while (run + 1 < kNRun && f0 >= s_base[run + 1]) ++run;
-                    int myrun = run;
-                    while (myrun + 1 < kNRun && f >= s_base[myrun + 1]) ++myrun;
-                    const uint32_t o = f - s_base[myrun];
-                    if (!(ABL & 2) && f < T && o < s_len[myrun]) rec[u] = *reinterpret_cast<const float4 *>(&srecs[s_g0[myrun] + o]);
+            for (int u = 0; u < 3; ++u) {
+                const int r = r0 + u * nw;
+                rb[u] = rl[u] = rg[u] = 0u;
+                if (r < kNRun) {                                       // wave-uniform
+                    rb[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_base[r]);      // wave-uniform: scalar registers
+                    rl[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_len[r]);
+                    rg[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_g0[r]);
                 }
+                rec[u] = make_float4(kFar, kFar, kFar, __int_as_float(-1));                // the pad of an odd run
+                if (!(ABL & 2) && (uint32_t)lane < rl[u]) rec[u] = *reinterpret_cast<const float4 *>(&srecs[rg[u] + (uint32_t)lane]);
             }
+            const int xu = lane / kExtra;                              // 0..2 (lane 63: 3 = nobody)
+            const uint32_t xp = 64u + (uint32_t)(lane - xu * kExtra);
+            const uint32_t xb = xu == 0 ? rb[0] : xu == 1 ? rb[1] : rb[2];
+            const uint32_t xl = xu == 0 ? rl[0] : xu == 1 ? rl[1] : xu == 2 ? rl[2] : 0u;
+            const uint32_t xg = xu == 0 ? rg[0] : xu == 1 ? rg[1] : rg[2];
+            rex = make_float4(kFar, kFar, kFar, __int_as_float(-1));
+            if (!(ABL & 2) && xp < xl) rex = *reinterpret_cast<const float4 *>(&srecs[xg + xp]);
             // b. cell-start loads of this wave's runs
             uint32_t v[3][2];
             bool in[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const int r = (int)r0 + u * nw;
+                const int r = r0 + u * nw;
                 v[u][0] = v[u][1] = 0u;
                 in[u] = false;
                 if (r < kNRun) {                                       // wave-uniform
@@ -229,19 +251,45 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
             }
             // c. the LDS writes (in the order the loads return)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (ff[u] < T) {
-                    float *d = s_f + (ff[u] >> 1) * 8 + (ff[u] & 1u);
+            for (int u = 0; u < 3; ++u) {
+                const uint32_t plen = (rl[u] + 1u) & ~1u;
+                if ((uint32_t)lane < plen) {
+                    const uint32_t f = rb[u] + (uint32_t)lane;
+                    float *d = s_f + (f >> 1) * 8 + (f & 1u);
                     d[0] = rec[u].x;
                     d[2] = rec[u].y;
                     d[4] = rec[u].z;
                     d[6] = rec[u].w;
                 }
+            }
+            if (xp < ((xl + 1u) & ~1u)) {
+                const uint32_t f = xb + xp;
+                float *d = s_f + (f >> 1) * 8 + (f & 1u);
+                d[0] = rex.x;
+                d[2] = rex.y;
+                d[4] = rex.z;
+                d[6] = rex.w;
+            }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const int r = (int)r0 + u * nw;
+                // a run of more than 64 + kExtra records (crowded rows): the rest, piece by piece
+                const uint32_t plen = (rl[u] + 1u) & ~1u;
+                for (uint32_t p = (uint32_t)lane + 64u + (uint32_t)kExtra; p < plen; p += 64u) {
+                    float4 t = make_float4(kFar, kFar, kFar, __int_as_float(-1));
+                    if (!(ABL & 2) && p < rl[u]) t = *reinterpret_cast<const float4 *>(&srecs[rg[u] + p]);
+                    const uint32_t f = rb[u] + p;
+                    float *d = s_f + (f >> 1) * 8 + (f & 1u);
+                    d[0] = t.x;
+                    d[2] = t.y;
+                    d[4] = t.z;
+                    d[6] = t.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int r = r0 + u * nw;
                 if (r < kNRun) {
-                    const uint32_t base = s_base[r], rebase = base - s_g0[r];
+                    const uint32_t base = rb[u], rebase = base - rg[u];
                     if (lane <= ncs) s_lcs[r * kLcsPitch + lane] = (uint16_t)(in[u] ? v[u][0] + rebase : base);
                     if (lane + 64 <= ncs) s_lcs[r * kLcsPitch + lane + 64] = (uint16_t)(in[u] ? v[u][1] + rebase : base);
                 }
@@ -251,8 +299,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         //    travels while the workgroup meets at the barrier and scans
         __builtin_amdgcn_sched_barrier(0);
         if (have && fuse_row) {
-            const double *np = out.nrm + 3 * (int64_t)__float_as_int(qn.w);
-            n0 = np[0]; n1 = np[1]; n2 = np[2];
+            load_normal(out, __float_as_int(qn.w), n0, n1, n2);
         }
     }
     BRICK_STAMP(1);                                                    // staging issued (+ waits of its loads)
@@ -338,8 +385,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
                 if (fuse) {
                     double e0 = m0, e1 = m1, e2 = m2;
                     if (!fuse_row) {
-                        const double *np = out.nrm + 3 * (int64_t)wrow;
-                        e0 = np[0]; e1 = np[1]; e2 = np[2];
+                        load_normal(out, wrow, e0, e1, e2);
                     }
                     const double ex = __dsub_rn(qx, rx), ey = __dsub_rn(qy, ry), ez = __dsub_rn(qz, rz);
                     p = __dmul_rn(ex, e0);
@@ -357,8 +403,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
             rn = query_row(qnext);
             qn = load_query(qnext, rn);
             if (fuse_row) {
-                const double *np = out.nrm + 3 * (int64_t)__float_as_int(qn.w);
-                n0 = np[0]; n1 = np[1]; n2 = np[2];
+                load_normal(out, __float_as_int(qn.w), n0, n1, n2);
             }
         }
         qi = qnext;

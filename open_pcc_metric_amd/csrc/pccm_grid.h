@@ -119,6 +119,7 @@ struct NNOut {
     double *rec;           // [rows of the shard][stride], indexed row - row_base
     int stride;            // doubles per record: 4 = {d2, projection, row bits, -}, 2 = {d2, projection}
     const double *nrm;     // normals of the searched cloud, [.][3], or null: projection not fused
+    const float4 *nrm32;   // the same normals as aligned 16-byte words when they are fp32-exact (the brick kernel's gather), or null
     int64_t row_base;
     int normal_mode;       // PCCM_NORMAL_ROW / PCCM_NORMAL_NEIGHBOUR
 };

@@ -1055,6 +1055,8 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         J.out.rec = (double *)res.rec.p;
         J.out.stride = res.rec_stride;
         J.out.nrm = fm >= 0 ? se.nrm64 : nullptr;
+        static const bool nrm32_off = [] { const char *e = getenv("PCCM_NRM32"); return e && e[0] == '0'; }();
+        J.out.nrm32 = (fm >= 0 && se.nrm_exact32 && !nrm32_off) ? se.nrm32 : nullptr;
         J.out.row_base = res.begin;
         J.out.normal_mode = fm >= 0 ? fm : PCCM_NORMAL_ROW;
         res.fused_mode = fm;

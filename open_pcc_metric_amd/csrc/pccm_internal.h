@@ -29,12 +29,14 @@ struct Cloud {
     float4 *xyz32 = nullptr;    // [n_pad/4][3] quads: x0..3 | y0..3 | z0..3; padding rows = kPadCoord
     double *xyz64 = nullptr;    // [n][3]
     double *nrm64 = nullptr;    // [n_nrm][3]
+    float4 *nrm32 = nullptr;    // [n_nrm] {nx, ny, nz, -}: the same normals in one aligned 16-byte word each, when nrm_exact32
+    bool nrm_exact32 = false;   // every component survives fp64 -> fp32 -> fp64 (file normals usually do; estimated ones do not)
     int64_t n_nrm = 0;
     double *rgb64 = nullptr;    // [n_rgb][3] colours as the caller gave them (RGB in [0, 1])
     int64_t n_rgb = 0;
     // allocations outlive their content (n / n_nrm / n_rgb say what is there): a context that serves one pair after
     // the other -- the engine pool of _native.py -- does not pay hipFree + hipMalloc per cloud
-    size_t cap32 = 0, cap64 = 0, cap_nrm = 0, cap_rgb = 0;
+    size_t cap32 = 0, cap64 = 0, cap_nrm = 0, cap_nrm32 = 0, cap_rgb = 0;
     bool exact32 = true;        // every coordinate survives the fp64 -> fp32 -> fp64 round trip
     bool all_int = false;       // ... and is an integer (voxelised content: exact ties are the rule)
     double maxabs = 0.0;
@@ -215,7 +217,7 @@ struct ProfScope {   // records a HIP-event pair around a launch group when prof
 // kernel launchers (each returns PCCM_OK or an error) -----------------------------------
 int launch_ingest_points(pccm_ctx *ctx, const void *src, int dtype, int64_t n, int64_t n_pad, float4 *x32,
                          double *x64, unsigned long long *stats /*[3] device*/);
-int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, double *out,
+int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, double *out, float *out32,
                           unsigned long long *stats);
 
 // brute-force engine: fills res.idx / res.d2 for rows [res.begin, res.end) of `it` searched in `se`

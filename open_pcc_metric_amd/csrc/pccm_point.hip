@@ -103,17 +103,21 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_ingest_normals(const T *__restrict__ src, int64_t n3,
-                                                        double *__restrict__ out,
+                                                        double *__restrict__ out, float *__restrict__ out32,
                                                         unsigned long long *__restrict__ stats)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int bad = 0;
+    int bad = 0, inexact = 0;
     if (i < n3) {
         double v = (double)src[i];
         out[i] = v;
+        const float f = (float)v;
+        if (out32) out32[(i / 3) * 4 + (i % 3)] = f;      // stats[1] says whether this copy may stand for `out`
         bad = isfinite(v) ? 0 : 1;
+        inexact = ((double)f == v) ? 0 : 1;
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicAdd(&stats[2], 1ull);
+    if (__ballot(inexact) && (threadIdx.x & 63) == 0) atomicAdd(&stats[1], 1ull);
 }
 
 int launch_ingest_points(pccm_ctx *ctx, const void *src, int dtype, int64_t n, int64_t n_pad, float4 *x32,
@@ -130,15 +134,15 @@ int launch_ingest_points(pccm_ctx *ctx, const void *src, int dtype, int64_t n, i
     return PCCM_OK;
 }
 
-int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, double *out, unsigned long long *stats)
+int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, double *out, float *out32, unsigned long long *stats)
 {
     ProfScope ps(ctx, PCCM_K_INGEST);
     const int64_t n3 = 3 * n;
     dim3 grid((unsigned)((n3 + 255) / 256));
     if (dtype == PCCM_F32)
-        hipLaunchKernelGGL((k_ingest_normals<float>), grid, dim3(256), 0, ctx->stream, (const float *)src, n3, out, stats);
+        hipLaunchKernelGGL((k_ingest_normals<float>), grid, dim3(256), 0, ctx->stream, (const float *)src, n3, out, out32, stats);
     else
-        hipLaunchKernelGGL((k_ingest_normals<double>), grid, dim3(256), 0, ctx->stream, (const double *)src, n3, out, stats);
+        hipLaunchKernelGGL((k_ingest_normals<double>), grid, dim3(256), 0, ctx->stream, (const double *)src, n3, out, out32, stats);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }

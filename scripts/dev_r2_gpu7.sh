@@ -1,34 +1,27 @@
 #!/bin/bash
+# round-2 dev: 16-byte fp32-exact normals in the brick kernel's gather (A/B), build tile size with bin cursors, host-side changes
 set -o pipefail
-mkdir -p gpurun_out/r2g
 cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r2g; mkdir -p $O
 export TMPDIR=/tmp
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r2g/smoke.log 2>&1 || { echo SMOKE FAILED; tail -20 gpurun_out/r2g/smoke.log; exit 1; }
-tail -1 gpurun_out/r2g/smoke.log
-timeout -k 10 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_fuzz.py -x -q > gpurun_out/r2g/parity.log 2>&1; echo "parity rc=$? $(tail -1 gpurun_out/r2g/parity.log)"
-for v in 4,2,512 4,2,576 2,2,256; do
-  PCCM_BRICK=$v PCCM_BRICK_STAMP=1 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-extras > gpurun_out/r2g/stamp_$v.json 2> gpurun_out/r2g/stamp_$v.err
-  echo "variant $v"; grep "brick stamps" gpurun_out/r2g/stamp_$v.err | tail -1
-done
-run() {  # name, env...
-  name=$1; shift
-  env "$@" timeout -k 10 300 python bench.py --steps 40 --no-graph --no-cpu-baseline --no-extras > gpurun_out/r2g/bench_$name.json 2> gpurun_out/r2g/bench_$name.err
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { echo SMOKE FAILED; tail -20 $O/smoke.log; exit 1; }
+tail -1 $O/smoke.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; rc=$?; echo "gpu tests rc=$rc $(tail -1 $O/gpu_tests.log)"
+[ $rc -eq 0 ] || { tail -60 $O/gpu_tests.log; exit 1; }
+run() {  # name, mode flags, env...
+  name=$1; shift; flags=$1; shift
+  env "$@" timeout -k 10 300 python bench.py --steps 100 $flags --no-extras --no-cpu-baseline > $O/bench_$name.json 2> $O/bench_$name.err || { echo "$name FAILED"; tail -5 $O/bench_$name.err; return; }
   python - <<PY
 import json
-try:
-    d=json.load(open("gpurun_out/r2g/bench_$name.json"))
-    print("$name eager ms/step", d["ms_per_step"], d["kernel_us_per_step"])
-except Exception as e:
-    print("$name FAILED", e, open("gpurun_out/r2g/bench_$name.err").read()[-400:])
+d=json.load(open("$O/bench_$name.json"))
+print("$name ms/step", d["ms_per_step"], d.get("kernel_us_per_step"), d["roofline"]["frac"])
 PY
 }
-run default X=1
-run nt512 PCCM_BRICK=4,2,512
-run nt384 PCCM_BRICK=4,2,384
-run nt256 PCCM_BRICK=4,2,256
-run b22_256 PCCM_BRICK=2,2,256
-run b44_1024 PCCM_BRICK=4,4,1024
-run b44_512 PCCM_BRICK=4,4,512
-run bx22_256 PCCM_BRICK_BX=22 PCCM_BRICK=4,2,256
-timeout -k 10 300 python bench.py --steps 100 --no-cpu-baseline --no-extras > gpurun_out/r2g/bench_graph.json 2> gpurun_out/r2g/bench_graph.err; python -c "
-import json; d=json.load(open('gpurun_out/r2g/bench_graph.json')); print('graph ms/step', d['ms_per_step'], d['kernel_us_per_step'])"
+run graph_default "" X=1
+run graph_nrm64 "" PCCM_NRM32=0
+run graph_tile2048 "" PCCM_BUILD_TILE=2048
+run graph_tile8192 "" PCCM_BUILD_TILE=8192
+run graph_default2 "" X=1
+run eager_default --no-graph X=1
+run eager_nrm64 --no-graph PCCM_NRM32=0
+timeout -k 10 300 python scripts/host_split.py --points 1000000 2>&1 | tail -1

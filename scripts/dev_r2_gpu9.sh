@@ -1,27 +1,22 @@
 #!/bin/bash
+# round-2 dev: brick staging per run (wave w copies runs w, w+8, w+16) -- parity + bench
 set -o pipefail
-mkdir -p gpurun_out/r2i
 cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r2i; mkdir -p $O
 export TMPDIR=/tmp
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r2i/smoke.log 2>&1 || { echo SMOKE FAILED; tail -20 gpurun_out/r2i/smoke.log; exit 1; }
-tail -1 gpurun_out/r2i/smoke.log
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r2i/pytest.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/r2i/pytest.log)"
-run() {  # name, env...
-  name=$1; shift
-  env "$@" timeout -k 10 300 python bench.py --steps 40 --no-graph --no-cpu-baseline --no-extras > gpurun_out/r2i/bench_$name.json 2> gpurun_out/r2i/bench_$name.err
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { echo SMOKE FAILED; tail -20 $O/smoke.log; exit 1; }
+tail -1 $O/smoke.log
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_round2.py -x -q > $O/parity.log 2>&1; rc=$?; echo "parity rc=$rc $(tail -1 $O/parity.log)"
+[ $rc -eq 0 ] || { tail -40 $O/parity.log; exit 1; }
+run() {  # name, mode flags, env...
+  name=$1; shift; flags=$1; shift
+  env "$@" timeout -k 10 300 python bench.py --steps 100 $flags --no-extras --no-cpu-baseline > $O/bench_$name.json 2> $O/bench_$name.err || { echo "$name FAILED"; tail -5 $O/bench_$name.err; return; }
   python - <<PY
 import json
-try:
-    d=json.load(open("gpurun_out/r2i/bench_$name.json"))
-    print("$name eager ms/step", d["ms_per_step"], d["kernel_us_per_step"])
-except Exception as e:
-    print("$name FAILED", e, open("gpurun_out/r2i/bench_$name.err").read()[-400:])
+d=json.load(open("$O/bench_$name.json"))
+print("$name ms/step", d["ms_per_step"], d.get("kernel_us_per_step"), d["roofline"]["frac"])
 PY
 }
-run default X=1
-run lg11 PCCM_BUILD_LG=11
-run lg12 PCCM_BUILD_LG=12
-run lg13 PCCM_BUILD_LG=13
-run lg12t4096 PCCM_BUILD_LG=12 PCCM_BUILD_TILE=4096
-run t4096 PCCM_BUILD_TILE=4096
-timeout -k 10 600 python scripts/rank_profile.py > gpurun_out/r2i/rank_profile.log 2>&1; grep -v "^{" gpurun_out/r2i/rank_profile.log | tail -20
+run graph_default "" X=1
+run graph_default2 "" X=1
+run eager_default --no-graph X=1

@@ -58,6 +58,40 @@ def test_fused_projection_equals_the_separate_pass(engine, mode, n, m):
         assert np.array_equal(fi, idx) and np.array_equal(fd, d2)            # result records unpack to the plain columns
 
 
+@pytest.mark.parametrize("mode", ["row", "neighbour"])
+def test_normals_in_fp32_words_or_fp64_rows_same_projection(engine, mode):
+    """The brick kernel gathers fp32-exact normals as one aligned 16-byte word and anything else as three fp64 values:
+    float32 input, float64 input that happens to be fp32-exact, and float64 input that is not all give the oracle's
+    projections bit for bit -- and one inexact component is enough to leave the short form."""
+    n = 50_000
+    rng = np.random.default_rng(77)
+    a, b = rng.random((n, 3), dtype=np.float32), rng.random((n, 3), dtype=np.float32)
+    na32, nb32 = _unit(n, 5), _unit(n, 6)
+    noisy_a = na32.astype(np.float64) + rng.normal(0, 1e-9, (n, 3))
+    one_off_b = nb32.astype(np.float64)
+    one_off_b[n // 2, 1] += 2.0 ** -40
+    want = {}
+    for name, (xa, xb) in {"f32": (na32, nb32), "f64 exact": (na32.astype(np.float64), nb32.astype(np.float64)),
+                           "f64 inexact": (noisy_a, one_off_b)}.items():
+        engine.set_cloud(0, a); engine.set_cloud(1, b)
+        engine.set_normals(0, xa); engine.set_normals(1, xb)
+        for d in (0, 1):
+            engine.nn_fuse(d, mode)
+        engine.drop_caches(); engine.nn_pair("grid")
+        for d in (0, 1):
+            it, se, nrm = (a, b, xb) if d == 0 else (b, a, xa)
+            key = (d, name if name == "f64 inexact" else "exact")
+            if key not in want:
+                idx, _ = orc.nn(it.astype(np.float64), se.astype(np.float64), method="kdtree")
+                want[key] = orc.point_to_plane(it.astype(np.float64), se.astype(np.float64), idx, np.asarray(nrm, dtype=np.float64),
+                                               normal_index=mode)
+            proj = want[key]
+            assert np.array_equal(engine.point_metric(d, nat.METRIC_PROJ, mode), proj), (name, d)
+            total = engine.reduce_total(d, nat.METRIC_D2, mode)
+            assert same_bits(total[0], np.sum(np.square(proj))) and same_bits(total[2], np.max(np.square(proj))), (name, d)
+    assert not np.array_equal(want[(1, "exact")], want[(1, "f64 inexact")])       # the perturbation is visible in the result
+
+
 def test_results_without_rows_and_rows_on_demand(engine):
     """pccm_nn_want_idx off: 16-byte result records, identical reductions; the first caller that asks for the matched rows
     gets them from a repeated search of that direction -- same bits as with the rows on from the start."""
