@@ -254,7 +254,7 @@ def main():
                                        "frac": round(compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
     elif gq_n:
         avg_ms = gq_ms / gq_n
-        ncells = n / 1.5
+        ncells = float(stats[0]["splits"])      # grid engine: pccm_nn_stats reports the cells of the grid it searched
         # one launch serves BOTH directions (pccm_nn_pair).  DESIGN.md section 3, per direction and query:
         # its 16-byte record in, the row-indexed normal (24 B) in, ONE 16-byte result record (d2, projection; the matched
         # row is left out when nothing will read it: pccm_nn_want_idx) out = 56 B/query; per searched point its 16-byte
@@ -282,7 +282,7 @@ def main():
                    "engine": args.engine, "sharding": "none" if world == 1 else f"{args.shard_mode} x{args.gpus}",
                    "hip_graph": not args.no_graph,
                    "fallback_queries": [s["fallback_queries"] for s in stats],
-                   "scan_splits": [s["splits"] for s in stats]},
+                   ("grid_cells" if gq_n else "scan_splits"): [s["splits"] for s in stats]},
         "roofline": roofline, "roofline_measured_by": prof_leg,
         "kernel_us_per_step": {k: round(v[0] / prof_steps * 1e3, 1) for k, v in prof.items() if v[1]},
         "result_sample": {"GeoMSE_sym_d1": float(result[("SymmetricMetric", "GeoMSE", True, False, "GeoMSE", False, False)]),

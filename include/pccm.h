@@ -270,7 +270,8 @@ int pccm_profile_reset(pccm_ctx *ctx);
 int pccm_profile_get(pccm_ctx *ctx, int kernel_class, double *ms_total, int64_t *launches);
 
 /* Bookkeeping of the last pccm_nn() in `dir`: out[0] = queries sent to the exact fallback
- * rescan, out[1] = ref-axis splits, out[2] = (query, ref) pairs evaluated by the scan. */
+ * rescan, out[1] = ref-axis splits of the brute-force scan / number of cells of the grid the
+ * grid engine searched, out[2] = (query, ref) pairs evaluated by the brute-force scan (grid: 0). */
 int pccm_nn_stats(pccm_ctx *ctx, int dir, int64_t out[3]);
 
 #ifdef __cplusplus

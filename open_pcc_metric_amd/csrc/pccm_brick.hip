@@ -47,6 +47,7 @@ struct BrickParams {
     int bx;                 // cells per brick along x
     int nbx, nby, nbz;      // bricks per axis
     int64_t per_job;        // nbx * nby * nbz
+    uint32_t m_nbx, m_nby;  // floor(2^32 / d) + 1 for d = nbx, nby: brick -> (x, y, z) by multiply-high on the scalar unit (0: divide)
     uint32_t total;         // bricks of all jobs
     int cap;                // staged records that fit (< 65536: LDS positions are kept as uint16)
     unsigned long long *stamps;   // diagnostic build only (PCCM_BRICK_STAMP=1): per-phase wave-cycle sums, else null
@@ -62,6 +63,13 @@ struct BrickParams {
             t_last = now_;                                                                   \
         }                                                                                    \
     } while (0)
+
+__device__ __forceinline__ float vmin(float a, float b)      // both finite here
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // the normal of `row`: one aligned 16-byte word when the cloud's normals are fp32-exact (exact widening), else 24 bytes of fp64
 __device__ __forceinline__ void load_normal(const NNOut &o, int row, double &a, double &b, double &c)
@@ -91,7 +99,8 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
     __shared__ uint16_t s_lcs[kNRun * kLcsPitch];
     __shared__ uint32_t s_g0[kNRun], s_len[kNRun], s_base[kNRun + 1], s_qg0[kNRow], s_qoff[kNRow + 1];
     float *const s_f = reinterpret_cast<float *>(s_rec);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform by construction: everything derived from it is scalar
     // XCD-aware order: workgroups b, b+8, ... share an XCD; give every XCD one contiguous eighth of the brick list
     const uint32_t nblk = bp.total, xcd = vblock & 7u, slot = vblock >> 3;
     const uint32_t bq = nblk >> 3, br = nblk & 7u;
@@ -101,7 +110,12 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
     if (vb >= bp.per_job) return;
     const QueryJob &J = jobs.j[jb];
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
-    const int ibx = (int)(vb % bp.nbx), iby = (int)((vb / bp.nbx) % bp.nby), ibz = (int)(vb / ((int64_t)bp.nbx * bp.nby));
+    // brick -> (x, y, z): n / d = mulhi(n, floor(2^32 / d) + 1) exactly while n d < 2^32 (the host checks); the 64-bit
+    // divisions this replaces were 360 scalar and 50 vector instructions per wave
+    const uint32_t vbu = (uint32_t)vb;
+    const uint32_t t_xy = bp.m_nbx ? (bp.nbx == 1 ? vbu : __umulhi(vbu, bp.m_nbx)) : vbu / (uint32_t)bp.nbx;
+    const uint32_t t_z = bp.m_nby ? (bp.nby == 1 ? t_xy : __umulhi(t_xy, bp.m_nby)) : t_xy / (uint32_t)bp.nby;
+    const int ibx = (int)(vbu - t_xy * (uint32_t)bp.nbx), iby = (int)(t_xy - t_z * (uint32_t)bp.nby), ibz = (int)t_z;
     const int bx0 = ibx * bp.bx, bx1 = min(bx0 + bp.bx, dimx);
     const int by0 = iby * BY, bz0 = ibz * BZ;
     const int sx0 = max(bx0 - 1, 0), sx1 = min(bx1 + 1, dimx);
@@ -354,14 +368,16 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
                         d0 = (__float_as_int(cb.z) == qrow) ? kBigF : d0;
                         d1 = (__float_as_int(cb.w) == qrow) ? kBigF : d1;
                     }
+                    // best / second over both candidates; the winner is remembered per SLOT (which of its two records it
+                    // was is found again after the scan: the same arithmetic gives the same bits) -- 6 VALU where tracking
+                    // the record itself took 9
+                    // (v_min_f32 by hand: for fminf hipcc canonicalises the loop-carried operand first, one more VALU)
+                    const float bprev = best;
                     second = __builtin_amdgcn_fmed3f(best, second, d0);
-                    const bool u0 = d0 < best;
-                    best = u0 ? d0 : best;
-                    bestpos = u0 ? a : bestpos;
+                    best = vmin(best, d0);
                     second = __builtin_amdgcn_fmed3f(best, second, d1);
-                    const bool u1 = d1 < best;
-                    best = u1 ? d1 : best;
-                    bestpos = u1 ? a + 4u : bestpos;
+                    best = vmin(best, d1);
+                    bestpos = best < bprev ? a : bestpos;
                 }
             }
         }
@@ -375,7 +391,20 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
             if (best < 0.0f) store_result(out, qrow, 0.0, 0.0, 0);     // never true: keeps the scan alive
             settled = true;
         } else if (bestpos != 0xffffffffu && best < 1.0e30f && second > thr) {          // (a pad record is no neighbour)
-            const float *c = s_f + ((bestpos - lds0) >> 2);         // byte address of the winner's x in its slot
+            // the winning slot's two records again: which one has d32 == best?  (both: then second == best and the
+            // certificate above has already failed)
+            const float *c = s_f + ((bestpos - lds0) >> 2);         // byte address of the slot
+            {
+                const float4 ca = *reinterpret_cast<const float4 *>(c), cb = *reinterpret_cast<const float4 *>(c + 4);
+                const v2f dx = qxx - v2f{ca.x, ca.y}, dy = qyy - v2f{ca.z, ca.w}, dz = qzz - v2f{cb.x, cb.y};
+                v2f dd = dx * dx;
+                dd = __builtin_elementwise_fma(dy, dy, dd);
+                dd = __builtin_elementwise_fma(dz, dz, dd);
+                float d0 = dd.x;
+                if (SELF) d0 = (__float_as_int(cb.z) == qrow) ? kBigF : d0;
+                const bool first = d0 == best;
+                c += first ? 0 : 1;
+            }
             const double rx = (double)c[0], ry = (double)c[2], rz = (double)c[4];
             const int wrow = __float_as_int(c[6]);
             const double d64 = gdist64(qx, qy, qz, rx, ry, rz);
@@ -535,12 +564,13 @@ int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, 
 {
     BrickParams bp;
     static const int bx_env = [] { const char *e = getenv("PCCM_BRICK_BX"); return e ? atoi(e) : 0; }();
-    const int bx_max = bx_env > 0 ? bx_env : 48;          // bricks of <= 48 cells: ~70 records per staged run at 1.5 points per cell
+    const int bx_max = bx_env > 0 ? bx_env : 48;          // bricks of <= 48 cells: ~65 records per staged run at 1.4 points per cell
     const int nbx = (g.dim[0] + bx_max - 1) / bx_max;
     bp.bx = (g.dim[0] + nbx - 1) / nbx;
     if (bp.bx > kBXMax) bp.bx = kBXMax;
     bp.nbx = (g.dim[0] + bp.bx - 1) / bp.bx;
     bp.nby = bp.nbz = 0;
+    bp.m_nbx = bp.m_nby = 0u;
     bp.per_job = 0;
     bp.total = 0;
     bp.cap = 0;

@@ -436,8 +436,10 @@ static double points_per_cell()
 {
     static double k = [] {
         const char *e = getenv("PCCM_GRID_PPC");
-        double v = e ? atof(e) : 1.5;
-        return (v > 0.05 && v < 64.0) ? v : 1.5;
+        // 1.4 points per cell: per step at 1M / 4M / 8M points 0.250 / 0.763 / 1.627 ms (1.5: 0.252 / 0.768 / 1.634; 1.3: 0.251 / 0.822 /
+        // 1.639; 1.2: 0.253 / 0.803 / 1.825 -- fewer candidates per query, but more tails and more cell starts)
+        double v = e ? atof(e) : 1.4;
+        return (v > 0.05 && v < 64.0) ? v : 1.4;
     }();
     return k;
 }
@@ -1072,7 +1074,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         job_of_dir[dir] = dst.njobs;
         (dir == PCCM_DIR_SELF ? self_dirs : normal_dirs)[dst.njobs] = dir;
         dst.j[dst.njobs++] = J;
-        res.stats[1] = 0;
+        res.stats[1] = gr.ncells;       // pccm_nn_stats: the grid this search ran on (the bench's byte count needs it)
         res.stats[2] = 0;
     }
     if (nshard > 0) {

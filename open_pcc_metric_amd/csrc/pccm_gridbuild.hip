@@ -185,33 +185,33 @@ __device__ __forceinline__ int tile_job(const BinPlan &P, int64_t &tile)
 }
 
 template <bool X32, bool CUR>
-__global__ __launch_bounds__(256) void k_bin_count(BinPlan P, GridGeom g, uint32_t *__restrict__ hist)
+__global__ __launch_bounds__(1024) void k_bin_count(BinPlan P, GridGeom g, uint32_t *__restrict__ hist)
 {
     extern __shared__ uint32_t s_hist[];                  // [nbin]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nth = (int)blockDim.x;     // 1024 threads: a tile is two trips of four rows per thread, all loads in flight
     if (!CUR && blockIdx.x == 0) {                                // the scan's sentinel and state: zero before the scan starts
         unsigned long long *state = reinterpret_cast<unsigned long long *>(hist + P.state_off);
         if (tid == 0) hist[P.hlen] = 0u;
-        for (int64_t k = tid; k < P.nstate; k += 256) state[k] = 0ull;
+        for (int64_t k = tid; k < P.nstate; k += nth) state[k] = 0ull;
     }
-    for (int b = tid; b < P.nbin; b += 256) s_hist[b] = 0u;
+    for (int b = tid; b < P.nbin; b += nth) s_hist[b] = 0u;
     __syncthreads();
     int64_t tile = blockIdx.x;
     const int jb = tile_job(P, tile);
     const BinJob &J = P.j[jb];
     const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
-    for (int64_t i = i0 + tid; i < i1; i += 1024) {       // four independent rows per trip
+    for (int64_t i = i0 + tid; i < i1; i += 4 * nth) {       // four independent rows per trip
         uint32_t bin[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t ii = i + 256 * k;
+            const int64_t ii = i + nth * k;
             double x, y, z;
             load_point<X32>(J, ii < i1 ? ii : i1 - 1, x, y, z);
             bin[k] = cell_linear(g, x, y, z) >> P.lg;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (i + 256 * k < i1) atomicAdd(&s_hist[bin[k]], 1u);
+            if (i + nth * k < i1) atomicAdd(&s_hist[bin[k]], 1u);
     }
     __syncthreads();
     if (CUR) {
@@ -219,84 +219,85 @@ __global__ __launch_bounds__(256) void k_bin_count(BinPlan P, GridGeom g, uint32
         // (tile, bin), 64 consecutive words per wave instruction; which tile comes first inside a bin is left to chance
         // (like the order inside a cell: no result depends on it)
         uint32_t *cur = P.cursor + (int64_t)jb * P.nbin, *dst = P.toff + (J.tile0 + tile) * P.nbin;
-        for (int b = tid; b < P.nbin; b += 256) {
+        for (int b = tid; b < P.nbin; b += nth) {
             const uint32_t c = s_hist[b];
             dst[b] = c ? atomicAdd(&cur[b], c) : 0u;
         }
         return;
     }
     uint32_t *dst = hist + J.hoff + tile;
-    for (int b = tid; b < P.nbin; b += 256) dst[(int64_t)b * J.nt] = s_hist[b];
+    for (int b = tid; b < P.nbin; b += nth) dst[(int64_t)b * J.nt] = s_hist[b];
 }
 
 __device__ __forceinline__ void block_scan_inplace(uint32_t *s_cnt, int nc, uint32_t *s_wsum, uint32_t *s_carry);
 
 template <typename REC, bool X32, bool CUR>
-__global__ __launch_bounds__(256) void k_bin_scatter(BinPlan P, GridGeom g, const uint32_t *__restrict__ hist, REC *__restrict__ tmp)
+__global__ __launch_bounds__(1024) void k_bin_scatter(BinPlan P, GridGeom g, const uint32_t *__restrict__ hist, REC *__restrict__ tmp)
 {
     extern __shared__ uint32_t s_cur[];                   // [nbin]: next free position of each bin's share of this tile
-    __shared__ uint32_t s_wsum[4], s_carry;
-    const int tid = threadIdx.x;
+    __shared__ uint32_t s_wsum[16], s_carry;
+    const int tid = threadIdx.x, nth = (int)blockDim.x;
     int64_t tile = blockIdx.x;
     const int jb = tile_job(P, tile);
     const BinJob &J = P.j[jb];
     if (CUR) {
         // every tile scans the job's bin totals itself (nbin <= 8192 words of LDS, a few barriers): no scan kernel
         const uint32_t *tot = P.cursor + (int64_t)jb * P.nbin, *off = P.toff + (J.tile0 + tile) * P.nbin;
-        uint32_t mine[4];                                 // this thread's first toff words, in flight during the scan
+        uint32_t mine[2];                                 // this thread's first toff words, in flight during the scan
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mine[k] = (tid + 256 * k < P.nbin) ? off[tid + 256 * k] : 0u;
-        for (int b = tid; b < P.nbin; b += 256) s_cur[b] = tot[b];
+        for (int k = 0; k < 2; ++k) mine[k] = (tid + nth * k < P.nbin) ? off[tid + nth * k] : 0u;
+        for (int b = tid; b < P.nbin; b += nth) s_cur[b] = tot[b];
         __syncthreads();
         block_scan_inplace(s_cur, P.nbin, s_wsum, &s_carry);
         if (tile == 0) {
             uint32_t *bs = P.bstart + (int64_t)jb * P.nbin;
-            for (int b = tid; b < P.nbin; b += 256) bs[b] = (uint32_t)J.base + s_cur[b];
+            for (int b = tid; b < P.nbin; b += nth) bs[b] = (uint32_t)J.base + s_cur[b];
         }
         if (blockIdx.x == 0) {                            // the sentinel, and the bins of a job without rows (it has no tile)
             const BinJob &L = P.j[P.njobs - 1];
             if (tid == 0) P.bstart[(int64_t)P.njobs * P.nbin] = (uint32_t)(L.base + L.n);
             for (int k = 0; k < P.njobs; ++k)
                 if (P.j[k].nt == 0)
-                    for (int b = tid; b < P.nbin; b += 256) P.bstart[(int64_t)k * P.nbin + b] = (uint32_t)P.j[k].base;
+                    for (int b = tid; b < P.nbin; b += nth) P.bstart[(int64_t)k * P.nbin + b] = (uint32_t)P.j[k].base;
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (tid + 256 * k < P.nbin) s_cur[tid + 256 * k] += (uint32_t)J.base + mine[k];
-        for (int b = tid + 1024; b < P.nbin; b += 256) s_cur[b] += (uint32_t)J.base + off[b];
+        for (int k = 0; k < 2; ++k)
+            if (tid + nth * k < P.nbin) s_cur[tid + nth * k] += (uint32_t)J.base + mine[k];
+        for (int b = tid + 2 * nth; b < P.nbin; b += nth) s_cur[b] += (uint32_t)J.base + off[b];
     } else {
         const uint32_t *src = hist + J.hoff + tile;
-        for (int b = tid; b < P.nbin; b += 256) s_cur[b] = src[(int64_t)b * J.nt];
+        for (int b = tid; b < P.nbin; b += nth) s_cur[b] = src[(int64_t)b * J.nt];
     }
     __syncthreads();
     const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
-    for (int64_t i = i0 + tid; i < i1; i += 1024) {
+    for (int64_t i = i0 + tid; i < i1; i += 4 * nth) {
         P3 v[4];
         uint32_t bin[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t ii = (i + 256 * k < i1) ? i + 256 * k : i1 - 1;
+            const int64_t ii = (i + nth * k < i1) ? i + nth * k : i1 - 1;
             load_point<X32>(J, ii, v[k].x, v[k].y, v[k].z);
             v[k].row = (int)(J.row0 + ii);
             bin[k] = cell_linear(g, v[k].x, v[k].y, v[k].z) >> P.lg;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (i + 256 * k < i1) {
+            if (i + nth * k < i1) {
                 const uint32_t pos = atomicAdd(&s_cur[bin[k]], 1u);
                 store_rec(tmp, pos, v[k]);
             }
     }
 }
 
-// block-wide exclusive scan of s_cnt[0..nc) in place (256 threads); returns nothing, leaves offsets
+// block-wide exclusive scan of s_cnt[0..nc) in place (any block of whole waves, s_wsum[16]); leaves offsets
 __device__ __forceinline__ void block_scan_inplace(uint32_t *s_cnt, int nc, uint32_t *s_wsum, uint32_t *s_carry)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) *s_carry = 0u;
     __syncthreads();
-    for (int base = 0; base < nc; base += 1024) {
+    const int nth = (int)blockDim.x;
+    for (int base = 0; base < nc; base += 4 * nth) {
         // four consecutive counters per thread: one 16-byte LDS access each way
         const int e = base + 4 * tid;
         uint32_t c0 = e < nc ? s_cnt[e] : 0u, c1 = e + 1 < nc ? s_cnt[e + 1] : 0u;
@@ -320,7 +321,7 @@ __device__ __forceinline__ void block_scan_inplace(uint32_t *s_cnt, int nc, uint
         run += c2;
         if (e + 3 < nc) s_cnt[e + 3] = run;
         __syncthreads();
-        if (tid == 255) *s_carry = run + c3;
+        if (tid == nth - 1) *s_carry = run + c3;
         __syncthreads();
     }
 }
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, sizeof(REC) == 16 ? 6 : 4) void k_bin_sort(Bin
                                                   REC *__restrict__ recs)
 {
     extern __shared__ uint32_t s_cnt[];                   // [cells of a bin]
-    __shared__ uint32_t s_wsum[4], s_carry;
+    __shared__ uint32_t s_wsum[16], s_carry;
     const int tid = threadIdx.x;
     const int jb = (P.njobs > 1 && (int)blockIdx.x >= P.nbin) ? 1 : 0;
     const int b = (int)blockIdx.x - jb * P.nbin;
@@ -446,6 +447,7 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
     P.nstate = st + 1;
     P.state_off = (P.hlen + 2) / 2 * 2;
     const size_t rsz = rec32 ? sizeof(Rec32) : sizeof(GridRec);
+    static const int bin_threads = [] { const char *e = getenv("PCCM_BUILD_THREADS"); int v = e ? atoi(e) : 1024; return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 1024; }();
     static const bool use_scan = [] { const char *e = getenv("PCCM_BUILD_SCAN"); return e && e[0] == '1'; }();   // A/B: round-2's first form (hist matrix + look-back scan)
     const bool cur = !use_scan && P.nbin <= 8192;
     const int64_t ncur = (int64_t)P.njobs * P.nbin;
@@ -475,17 +477,17 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
     const size_t lds_bins = (size_t)P.nbin * sizeof(uint32_t), lds_cells = ((size_t)1 << P.lg) * sizeof(uint32_t);
     if (P.ntiles > 0 && cur) {
         dim3 tg((unsigned)P.ntiles);
-        if (rec32) hipLaunchKernelGGL((k_bin_count<true, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
-        else hipLaunchKernelGGL((k_bin_count<false, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
-        if (rec32) hipLaunchKernelGGL((k_bin_scatter<Rec32, true, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (Rec32 *)ctx->g_tmp.p);
-        else hipLaunchKernelGGL((k_bin_scatter<GridRec, false, true>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (GridRec *)ctx->g_tmp.p);
+        if (rec32) hipLaunchKernelGGL((k_bin_count<true, true>), tg, dim3(bin_threads), lds_bins, ctx->stream, P, g, hist);
+        else hipLaunchKernelGGL((k_bin_count<false, true>), tg, dim3(bin_threads), lds_bins, ctx->stream, P, g, hist);
+        if (rec32) hipLaunchKernelGGL((k_bin_scatter<Rec32, true, true>), tg, dim3(bin_threads), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (Rec32 *)ctx->g_tmp.p);
+        else hipLaunchKernelGGL((k_bin_scatter<GridRec, false, true>), tg, dim3(bin_threads), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (GridRec *)ctx->g_tmp.p);
     } else if (P.ntiles > 0) {
         dim3 tg((unsigned)P.ntiles);
-        if (rec32) hipLaunchKernelGGL((k_bin_count<true, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
-        else hipLaunchKernelGGL((k_bin_count<false, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, hist);
+        if (rec32) hipLaunchKernelGGL((k_bin_count<true, false>), tg, dim3(bin_threads), lds_bins, ctx->stream, P, g, hist);
+        else hipLaunchKernelGGL((k_bin_count<false, false>), tg, dim3(bin_threads), lds_bins, ctx->stream, P, g, hist);
         hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)st), dim3(256), 0, ctx->stream, hist, P.hlen + 1, state, st);
-        if (rec32) hipLaunchKernelGGL((k_bin_scatter<Rec32, true, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (Rec32 *)ctx->g_tmp.p);
-        else hipLaunchKernelGGL((k_bin_scatter<GridRec, false, false>), tg, dim3(256), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (GridRec *)ctx->g_tmp.p);
+        if (rec32) hipLaunchKernelGGL((k_bin_scatter<Rec32, true, false>), tg, dim3(bin_threads), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (Rec32 *)ctx->g_tmp.p);
+        else hipLaunchKernelGGL((k_bin_scatter<GridRec, false, false>), tg, dim3(bin_threads), lds_bins, ctx->stream, P, g, (const uint32_t *)hist, (GridRec *)ctx->g_tmp.p);
     } else if (cur) {
         PCCM_HIP(hipMemsetAsync(P.bstart, 0, (size_t)(ncur + 1) * sizeof(uint32_t), ctx->stream));
     } else {

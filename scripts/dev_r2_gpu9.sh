@@ -20,3 +20,6 @@ PY
 run graph_default "" X=1
 run graph_default2 "" X=1
 run eager_default --no-graph X=1
+run graph_ppc1.2 "" PCCM_GRID_PPC=1.2
+run graph_ppc1.3 "" PCCM_GRID_PPC=1.3
+run graph_ppc1.7 "" PCCM_GRID_PPC=1.7
