@@ -412,12 +412,192 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
     for (int c = 0; c < J.ncols; ++c) J.c[c].out_tail[e] = v[c];
 }
 
+// The same reduction with the jobs' shape fixed at compile time (every report's jobs share one shape): record stride and
+// which field feeds which column are template arguments, so the sixteen loads of a lane are one base address + immediate
+// offsets and no value passes through a select.  CFG 0: two columns {field 0, field 1 squared} (D1 + D2 of a direction in
+// one pass over its result records), 1: field 0, 2: field 1 squared, 3: field 1.  (The general kernel above spends most of
+// its 20 us at 1M + 1M points on per-value selects, 64-bit index products and dependent scalar loads; a kernel of this
+// shape streams the same 32 MB in 7 us: scripts/micro/reduce_gap.hip.)
+__device__ __forceinline__ double dmin_raw(double a, double b)       // operands are finite: no canonicalisation needed
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double dmax_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int STRIDE, int CFG>
+__global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
+{
+    constexpr int NC = CFG == 0 ? 2 : 1;
+    __shared__ double ls[NC][32], lmn[NC][32], lmx[NC][32];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t unit_threads = jobs.uoff[jobs.njobs];
+    if ((int64_t)blockIdx.x * 256 < unit_threads) {            // block-uniform: jobs start at multiples of 256 lanes
+        int jb = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < jobs.njobs && (int64_t)blockIdx.x * 256 >= jobs.uoff[k]) jb = k;
+        const UnitJob &J = jobs.j[jb];
+        const double *__restrict__ val = J.val;
+        const int64_t ns = J.ns, nunits = J.nunits;
+        const int64_t u = (t - jobs.uoff[jb]) >> 3;
+        const int k = threadIdx.x & 7, grp = threadIdx.x >> 3;
+        const int64_t base = u * kLeaf;
+        const bool live = u < nunits;
+        const int64_t cnt = !live ? 0 : ((ns - base < kLeaf) ? ns - base : kLeaf);
+        double r[NC], mn[NC], mx[NC];
+        // column values of one record
+        auto cols = [](const double *p, double out[NC]) {
+            if (STRIDE >= 2) {
+                const double2 q = *reinterpret_cast<const double2 *>(p);
+                if (CFG == 0) { out[0] = q.x; out[1] = __dmul_rn(q.y, q.y); }
+                else if (CFG == 1) out[0] = q.x;
+                else if (CFG == 2) out[0] = __dmul_rn(q.y, q.y);
+                else out[0] = q.y;
+            } else {
+                out[0] = *p;
+            }
+        };
+        if (cnt == kLeaf) {
+            const double *p = val + (base + k) * STRIDE;
+            double v[kLeaf / 8][NC];
+#pragma unroll
+            for (int j = 0; j < kLeaf / 8; ++j) cols(p + (int64_t)j * 8 * STRIDE, v[j]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                r[c] = v[0][c];
+                mn[c] = mx[c] = v[0][c];
+#pragma unroll
+                for (int j = 1; j < kLeaf / 8; ++j) {
+                    r[c] = __dadd_rn(r[c], v[j][c]);
+                    mn[c] = dmin_raw(mn[c], v[j][c]);
+                    mx[c] = dmax_raw(mx[c], v[j][c]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { r[c] = 0.0; mn[c] = INFINITY; mx[c] = -INFINITY; }
+            for (int64_t e = k; e < cnt; e += 8) {
+                double w[NC];
+                cols(val + (base + e) * STRIDE, w);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    r[c] = __dadd_rn(r[c], w[c]);
+                    mn[c] = dmin_raw(mn[c], w[c]);
+                    mx[c] = dmax_raw(mx[c], w[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                r[c] = __dadd_rn(r[c], __shfl_xor(r[c], off));
+                mn[c] = dmin_raw(mn[c], __shfl_xor(mn[c], off));
+                mx[c] = dmax_raw(mx[c], __shfl_xor(mx[c], off));
+            }
+        }
+        if (k == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double *ou = J.c[c].out_units;
+                if (live && ou) {                          // per-leaf results: the sharded exchange needs them
+                    ou[u] = r[c];
+                    ou[nunits + u] = mn[c];
+                    ou[2 * nunits + u] = mx[c];
+                }
+                ls[c][grp] = r[c];
+                lmn[c][grp] = mn[c];
+                lmx[c][grp] = mx[c];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32 * NC) {
+            // this block's 32 leaves = one half of an 8192-row NumPy chunk: finish NumPy's pairwise tree for the half here
+            const int c = threadIdx.x >> 5, l = threadIdx.x & 31;
+            double s = ls[c][l], a = lmn[c][l], b = lmx[c][l];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                s = __dadd_rn(s, __shfl_xor(s, off));
+                a = dmin_raw(a, __shfl_xor(a, off));
+                b = dmax_raw(b, __shfl_xor(b, off));
+            }
+            if (l == 0) {
+                const int64_t blk = (t - jobs.uoff[jb]) >> 8;
+                double *ob = J.c[c].out_blocks;
+                ob[blk] = s;
+                ob[J.nblocks + blk] = a;
+                ob[2 * J.nblocks + blk] = b;
+            }
+        }
+        return;
+    }
+    // raw values of the last, partial 8192-row chunk (NumPy sums them with its own tree on the host)
+    const int64_t c0 = t - unit_threads;
+    if (c0 >= jobs.toff[jobs.njobs]) return;
+    int jb = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < jobs.njobs && c0 >= jobs.toff[k]) jb = k;
+    const UnitJob &J = jobs.j[jb];
+    const int64_t e = c0 - jobs.toff[jb];
+    const double *p = J.val + (J.tail_first + e) * STRIDE;
+    double w[NC];
+    if (STRIDE >= 2) {
+        const double2 q = *reinterpret_cast<const double2 *>(p);
+        if (CFG == 0) { w[0] = q.x; w[1] = __dmul_rn(q.y, q.y); }
+        else if (CFG == 1) w[0] = q.x;
+        else if (CFG == 2) w[0] = __dmul_rn(q.y, q.y);
+        else w[0] = q.y;
+    } else {
+        w[0] = *p;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) J.c[c].out_tail[e] = w[c];
+}
+
+// the shape all jobs of a launch share, or -1: (stride, CFG) as stride * 4 + cfg
+static int lean_shape(const UnitJobs &jobs)
+{
+    int shape = -1;
+    for (int k = 0; k < jobs.njobs; ++k) {
+        const UnitJob &J = jobs.j[k];
+        int cfg = -1;
+        if (J.stride == 1) cfg = (J.ncols == 1 && J.c[0].off == 0 && !J.c[0].square) ? 1 : -1;
+        else if (J.ncols == 2) cfg = (J.c[0].off == 0 && !J.c[0].square && J.c[1].off == 1 && J.c[1].square) ? 0 : -1;
+        else if (J.c[0].off == 0) cfg = J.c[0].square ? -1 : 1;
+        else cfg = J.c[0].square ? 2 : 3;
+        if (cfg < 0 || (J.stride != 1 && J.stride != 2 && J.stride != 4)) return -1;
+        const int sh = J.stride * 4 + cfg;
+        if (shape >= 0 && sh != shape) return -1;
+        shape = sh;
+    }
+    return shape;
+}
+
 int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
 {
     const int64_t total = jobs.uoff[jobs.njobs] + jobs.toff[jobs.njobs];
     if (total <= 0) return PCCM_OK;
     ProfScope ps(ctx, PCCM_K_REDUCE);
-    hipLaunchKernelGGL(k_unit_jobs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, jobs);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    static const bool general = [] { const char *e = getenv("PCCM_REDUCE_GENERAL"); return e && e[0] == '1'; }();   // A/B: always the general kernel
+    switch (general || jobs.variant != 0 ? -1 : lean_shape(jobs)) {
+    case 1 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<1, 1>), grid, block, 0, ctx->stream, jobs); break;
+    case 2 * 4 + 0: hipLaunchKernelGGL((k_unit_lean<2, 0>), grid, block, 0, ctx->stream, jobs); break;
+    case 2 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<2, 1>), grid, block, 0, ctx->stream, jobs); break;
+    case 2 * 4 + 2: hipLaunchKernelGGL((k_unit_lean<2, 2>), grid, block, 0, ctx->stream, jobs); break;
+    case 4 * 4 + 0: hipLaunchKernelGGL((k_unit_lean<4, 0>), grid, block, 0, ctx->stream, jobs); break;
+    case 4 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<4, 1>), grid, block, 0, ctx->stream, jobs); break;
+    case 4 * 4 + 2: hipLaunchKernelGGL((k_unit_lean<4, 2>), grid, block, 0, ctx->stream, jobs); break;
+    default: hipLaunchKernelGGL(k_unit_jobs, grid, block, 0, ctx->stream, jobs); break;      // mixed shapes; signed projections (min / max of -0.0 and 0.0: fmin / fmax there)
+    }
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
