@@ -363,14 +363,32 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
     const int lane = threadIdx.x & 63;
     const uint32_t wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
-    for (int jb = 0; jb < jobs.njobs; ++jb) {
+    // The first job's tail is handed out to the waves from the front, the second job's from the back (a wave that took an
+    // entry of each job in turn walked the chain of dependent round trips -- tail record, cell starts, records, winner --
+    // twice), and the list lengths travel together with the wave's first candidate entry of every job (an entry beyond
+    // its list's length is loaded and dropped: the buffers hold nq rows).
+    uint32_t cnt[2] = {0u, 0u}, start[2] = {wave0, nwaves - 1u - wave0};
+    P3 first[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        first[jb].x = first[jb].y = first[jb].z = 0.0;
+        first[jb].row = 0;
+        if (jb < jobs.njobs) {
+            const QueryJob &J = jobs.j[jb];
+            cnt[jb] = J.counters[1];
+            if ((int64_t)start[jb] < J.nq) first[jb] = load_rec((const REC *)J.tail, start[jb]);
+        }
+    }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        if (jb >= jobs.njobs) continue;
         const QueryJob &J = jobs.j[jb];
-        const uint32_t count = J.counters[1];
+        const uint32_t count = cnt[jb];
         if (count > kTailWaveMax) continue;                 // long tail: thread_search handles it
         const uint32_t *__restrict__ cell_start = J.cs;
         const REC *__restrict__ srecs = (const REC *)J.srecs;
-        for (uint32_t qi = wave0; qi < count; qi += nwaves) {
-            const P3 qa = load_rec((const REC *)J.tail, qi);   // wave-uniform
+        for (uint32_t qi = start[jb]; qi < count; qi += nwaves) {
+            const P3 qa = (qi == start[jb]) ? first[jb] : load_rec((const REC *)J.tail, qi);   // wave-uniform
             const double qx = qa.x, qy = qa.y, qz = qa.z;
             const int qrow = qa.row;
             const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
