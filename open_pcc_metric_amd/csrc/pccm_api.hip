@@ -1005,8 +1005,8 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         const double *base = stride >= 2 ? (const double *)res->rec.p : dev;
         UnitJob *host_job = nullptr;
         static const bool merge = [] {
-            const char *e = getenv("PCCM_REDUCE_MERGE"), *v = getenv("PCCM_REDUCE_VARIANT");
-            return !(e && e[0] == '0') && !(v && atoi(v) == 2);
+            const char *e = getenv("PCCM_REDUCE_MERGE");
+            return !(e && e[0] == '0');
         }();
         if (stride >= 2 && merge)
             for (int k = 0; k < uj.njobs; ++k)
@@ -1063,8 +1063,6 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
     UnitJobs uj;
     pj.njobs = 0; pj.off[0] = 0;
     uj.njobs = 0; uj.uoff[0] = 0; uj.toff[0] = 0;
-    static const int variant = [] { const char *e = getenv("PCCM_REDUCE_VARIANT"); return e ? atoi(e) : 0; }();
-    uj.variant = variant;
     ReduceSlot *fresh[8];
     int nfresh = 0;
     // first, whatever may change the layout of a direction's result records: a projection that was not fused into the

@@ -287,7 +287,6 @@ struct UnitJob {                // one per-point array to reduce (k_unit_jobs): 
 struct UnitJobs {
     UnitJob j[8];
     int njobs;
-    int variant;                // PCCM_REDUCE_VARIANT: load shape of the record fields (A/B runs; 0 = one 16-byte load)
     int64_t uoff[9];            // prefix sums of 8 * nunits, each rounded up to a multiple of 256
     int64_t toff[9];            // prefix sums of tail_n
 };

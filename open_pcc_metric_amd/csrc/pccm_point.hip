@@ -299,25 +299,12 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
         if (cnt == kLeaf) {
             double v[kLeaf / 8][2];
             // sixteen independent loads first; the layout test sits outside the loop so that they are issued together
-            if (V.stride >= 2 && jobs.variant == 0) {
+            if (V.stride >= 2) {
 #pragma unroll
                 for (int j = 0; j < kLeaf / 8; ++j) {
                     const double2 t = *reinterpret_cast<const double2 *>(&V.val[(base + 8 * j + k) * V.stride]);
                     v[j][0] = t.x;
                     v[j][1] = t.y;
-                }
-            } else if (V.stride >= 2 && jobs.variant == 1) {      // A/B: the two fields as two 8-byte loads
-#pragma unroll
-                for (int j = 0; j < kLeaf / 8; ++j) {
-                    v[j][0] = V.val[(base + 8 * j + k) * V.stride];
-                    v[j][1] = V.val[(base + 8 * j + k) * V.stride + 1];
-                }
-            } else if (V.stride >= 2) {                            // A/B: only the field of column 0 (unmerged jobs)
-#pragma unroll
-                for (int j = 0; j < kLeaf / 8; ++j) {
-                    const double t = V.val[(base + 8 * j + k) * V.stride + V.off0];
-                    v[j][0] = V.off0 ? 0.0 : t;
-                    v[j][1] = V.off0 ? t : 0.0;
                 }
             } else {
 #pragma unroll
@@ -588,7 +575,7 @@ int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
     ProfScope ps(ctx, PCCM_K_REDUCE);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     static const bool general = [] { const char *e = getenv("PCCM_REDUCE_GENERAL"); return e && e[0] == '1'; }();   // A/B: always the general kernel
-    switch (general || jobs.variant != 0 ? -1 : lean_shape(jobs)) {
+    switch (general ? -1 : lean_shape(jobs)) {
     case 1 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<1, 1>), grid, block, 0, ctx->stream, jobs); break;
     case 2 * 4 + 0: hipLaunchKernelGGL((k_unit_lean<2, 0>), grid, block, 0, ctx->stream, jobs); break;
     case 2 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<2, 1>), grid, block, 0, ctx->stream, jobs); break;

@@ -188,6 +188,37 @@ def test_clumped_bricks_and_leftovers_stay_exact(engine, monkeypatch):
         assert np.array_equal(d2, od) and np.array_equal(idx, oi)
 
 
+def test_long_runs_inside_the_lds_budget_stay_exact(engine, monkeypatch):
+    """A staged x-run of the brick kernel is copied 64 + 21 records at a time: thin dense lines along x inside uniform
+    data give runs of a few hundred records in bricks whose total still fits the LDS budget (the clump test above overflows
+    it instead).  Projections ride along (fp32-exact normals: the 16-byte gather)."""
+    rng = np.random.default_rng(21)
+    n = 250_000
+    a = rng.random((n, 3), dtype=np.float32)
+    b = rng.random((n, 3), dtype=np.float32)
+    for k, (y, z) in enumerate(((0.31, 0.42), (0.77, 0.18), (0.52, 0.93))):             # three lines of 1500 points each, both clouds
+        for c in (a, b):
+            rows = slice(2000 * k, 2000 * k + 1500)
+            c[rows, 0] = rng.random(1500, dtype=np.float32)
+            c[rows, 1] = np.float32(y) + np.float32(2e-4) * rng.standard_normal(1500).astype(np.float32)
+            c[rows, 2] = np.float32(z) + np.float32(2e-4) * rng.standard_normal(1500).astype(np.float32)
+    na, nb = _unit(n, 3), _unit(n, 4)
+    monkeypatch.setenv("PCCM_GRID_COOP", "1")
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    engine.set_normals(0, na); engine.set_normals(1, nb)
+    for d in (0, 1):
+        engine.nn_fuse(d, "row")
+    engine.nn_pair("grid"); engine.nn(2, "grid")
+    for d, (q, s, nrm, skip) in enumerate(((a, b, nb, False), (b, a, na, False), (a, a, None, True))):
+        idx, d2 = engine.fetch_nn(d)
+        oi, od = orc.nn(q.astype(np.float64), s.astype(np.float64), skip_same_index=skip, method="kdtree")
+        assert np.array_equal(d2, od) and np.array_equal(idx, oi)
+        if nrm is not None:
+            proj = orc.point_to_plane(q.astype(np.float64), s.astype(np.float64), oi, nrm.astype(np.float64), normal_index="row")
+            assert np.array_equal(engine.point_metric(d, nat.METRIC_PROJ, "row"), proj)
+            assert same_bits(engine.reduce_total(d, nat.METRIC_D2, "row")[0], np.sum(np.square(proj)))
+
+
 def test_cloud_pair_report_identical_with_and_without_fusion(monkeypatch):
     rng = np.random.default_rng(13)
     n = 120_000
