@@ -246,6 +246,7 @@ int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
         ctx->own_stream = true;
     }
     int rc = ensure(ctx, ctx->counters, 16 * sizeof(uint32_t));      // [0..5] per-direction counters, [8..11] rescan tickets
+    if (!rc && hipEventCreateWithFlags(&ctx->batch_ev, hipEventDisableTiming) != hipSuccess) rc = fail(PCCM_E_HIP, "hipEventCreate failed");
     if (!rc) rc = ensure(ctx, ctx->stats, 10 * sizeof(unsigned long long));
     if (!rc && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = fail(PCCM_E_HIP, "hipMemsetAsync failed");
@@ -268,6 +269,8 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
         (void)hipEventDestroy(s.b);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->batch_ev) (void)hipEventDestroy(ctx->batch_ev);
+    ctx->batch_ev = nullptr;
     for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
     for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
     DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->stats, &ctx->staging,
@@ -278,6 +281,7 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
         free_buf(s.val);
         if (s.host) (void)hipHostFree(s.host);
         if (s.ev) (void)hipEventDestroy(s.ev);
+        s.ev = s.wait_ev = nullptr;
     }
     grid_release(ctx);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1082,7 +1086,7 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
         if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
         if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k], want_units)) continue;
         ReduceSlot *s = slot_free(ctx);
-        if (s->pending && !ctx->capturing) PCCM_HIP(hipEventSynchronize(s->ev));
+        if (s->pending && !ctx->capturing && s->wait_ev) PCCM_HIP(hipEventSynchronize(s->wait_ev));
         s->pending = false;
         int rc = slot_prepare(ctx, *s, dirs[k], metrics[k], normal_modes[k], want_units, pj, uj);
         if (rc) return rc;
@@ -1103,9 +1107,10 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
             op.snap = s;
             ctx->cap_ops.push_back(op);
         } else {
-            PCCM_HIP(hipEventRecord(s.ev, ctx->stream));
+            s.wait_ev = ctx->batch_ev;
         }
     }
+    if (!ctx->capturing) PCCM_HIP(hipEventRecord(ctx->batch_ev, ctx->stream));      // one record for the whole batch
     return PCCM_OK;
 }
 
@@ -1127,7 +1132,7 @@ int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xve
         s = slot_find(ctx, dir, metric, normal_mode, true);
         if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
     }
-    PCCM_HIP(hipEventSynchronize(s->ev));
+    if (s->wait_ev) PCCM_HIP(hipEventSynchronize(s->wait_ev));
     s->pending = false;
     const int64_t n = s->n_iter;
     const int64_t xlen = pccm_xvec_len(n);
@@ -1187,7 +1192,7 @@ static int total_from_slot(pccm_ctx *ctx, int dir, int metric, int normal_mode, 
         s = slot_find(ctx, dir, metric, normal_mode);
         if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
     }
-    PCCM_HIP(hipEventSynchronize(s->ev));
+    if (s->wait_ev) PCCM_HIP(hipEventSynchronize(s->wait_ev));
     s->pending = false;
     const int64_t n = s->n_iter, nunits = s->nunits, nblocks = s->nblocks;
     const int64_t nfull = n / kChunk;
@@ -1328,18 +1333,18 @@ static int graph_replay(pccm_ctx *ctx, GraphRec &g)
             ctx->nn[op.dir].plain_d2_valid = op.plain_valid;
         } else if (op.kind == 2) {
             ReduceSlot &s = ctx->slots[op.slot];
-            if (s.pending && s.gen == ctx->nn_gen[s.dir]) PCCM_HIP(hipEventSynchronize(s.ev));   // still in use by someone else
+            if (s.pending && s.gen == ctx->nn_gen[s.dir] && s.wait_ev) PCCM_HIP(hipEventSynchronize(s.wait_ev));   // still in use by someone else
             s.dir = op.snap.dir; s.metric = op.snap.metric; s.mode = op.snap.mode;
             s.n_iter = op.snap.n_iter; s.begin = op.snap.begin; s.end = op.snap.end;
             s.nunits = op.snap.nunits; s.nblocks = op.snap.nblocks; s.has_units = op.snap.has_units;
             s.t0 = op.snap.t0; s.tail_n = op.snap.tail_n;
             s.gen = ctx->nn_gen[s.dir];
             s.pending = true;
+            s.wait_ev = ctx->batch_ev;
         }
     }
     PCCM_HIP(hipGraphLaunch(g.exec, ctx->stream));
-    for (auto &op : g.ops)
-        if (op.kind == 2) PCCM_HIP(hipEventRecord(ctx->slots[op.slot].ev, ctx->stream));
+    PCCM_HIP(hipEventRecord(ctx->batch_ev, ctx->stream));          // one record for every reduction of the graph
     return PCCM_OK;
 }
 
@@ -1395,7 +1400,8 @@ int pccm_graph_end(pccm_ctx *ctx, int *graph_id)
     // the captured calls changed the host bookkeeping but nothing ran yet: run the graph once now
     PCCM_HIP(hipGraphLaunch(g.exec, ctx->stream));
     for (auto &op : g.ops)
-        if (op.kind == 2) PCCM_HIP(hipEventRecord(ctx->slots[op.slot].ev, ctx->stream));
+        if (op.kind == 2) ctx->slots[op.slot].wait_ev = ctx->batch_ev;
+    PCCM_HIP(hipEventRecord(ctx->batch_ev, ctx->stream));
     int id = -1;
     for (size_t k = 0; k < ctx->graphs.size(); ++k)
         if (!ctx->graphs[k].valid && !ctx->graphs[k].exec) { id = (int)k; break; }

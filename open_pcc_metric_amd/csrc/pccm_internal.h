@@ -126,6 +126,8 @@ struct ReduceSlot {            // one enqueued reduction (pccm_reduce_prefetch /
     double *host = nullptr;    // pinned: [3][nunits] leaf sums/min/max | [3][nblocks] half-chunk trees | tail_n raw values
     size_t host_cap = 0;
     hipEvent_t ev = nullptr;
+    hipEvent_t wait_ev = nullptr;   // what says "this slot's numbers are on the host": the context's batch event (one record serves
+                                    // every slot of a call / of a graph replay; waiting on a later record of it only waits longer)
 };
 
 struct ProfSpan {
@@ -171,6 +173,7 @@ struct pccm_ctx {
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
     pccm::DevBuf g_bins, g_tmp;            // grid build: per-tile bin histogram + scan state; bin-partitioned records
+    hipEvent_t batch_ev = nullptr;   // recorded once behind every batch of reductions (ReduceSlot::wait_ev)
     bool bins_clean = false;   // the build's bin cursors (head of g_bins) are zero on the stream
     bool colsum_configured = false;        // k_color_colsum's dynamic-LDS opt-in was set on this context's device
     int want_idx = 1;                      // pccm_nn_want_idx: searches store the matched row with every result
