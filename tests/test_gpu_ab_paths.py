@@ -1,0 +1,29 @@
+"""The library keeps a few A/B switches (environment variables read once per process) next to its default paths: the
+look-back scan build, the general reduction kernel, fp64 normals in the fused projection, the per-thread / cooperative
+query kernels.  Each still has to give the oracle's report bit for bit -- one child process per switch."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("env", [
+    {"PCCM_BUILD_SCAN": "1"},
+    {"PCCM_REDUCE_GENERAL": "1"},
+    {"PCCM_NRM32": "0", "PCCM_BUILD_THREADS": "256"},
+    {"PCCM_GRID_COOP": "0"},
+    {"PCCM_GRID_REC64": "1"},
+    {"PCCM_NO_FUSE": "1", "PCCM_BUILD_TILE": "2048"},
+], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_ab_path_gives_the_same_report(env):
+    child = dict(os.environ)
+    child.update(env)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "ab_paths_check.py")], env=child, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "ab path ok" in out.stdout
