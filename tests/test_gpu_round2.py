@@ -219,6 +219,34 @@ def test_long_runs_inside_the_lds_budget_stay_exact(engine, monkeypatch):
             assert same_bits(engine.reduce_total(d, nat.METRIC_D2, "row")[0], np.sum(np.square(proj)))
 
 
+@pytest.mark.parametrize("margin,note", [(0.012, "several thousand tails: more than one entry per wave at both ends of the wave range"),
+                                         (0.05, "tens of thousands: the thread-per-query path")])
+def test_many_tail_queries_stay_exact(engine, monkeypatch, margin, note):
+    """Queries in a rim where the other cloud has no points cannot be settled by ring 1: they go through k_grid_finish
+    (one wave per entry, the two directions' lists handed out from opposite ends) or, past 16384 entries, through the
+    per-thread search; a few fall through to the exact rescan.  Every row is still the oracle's."""
+    rng = np.random.default_rng(31)
+    n = 300_000
+    a = (rng.random((n, 3), dtype=np.float32) * np.float32(1.0 + margin)).astype(np.float32)   # A pokes out of B's box
+    b = rng.random((n, 3), dtype=np.float32)
+    b[:, 2] = b[:, 2] * np.float32(1.0 + margin)                                               # ... and B out of A's along z only
+    a[:, 2] = np.minimum(a[:, 2], np.float32(1.0))
+    na, nb = _unit(n, 7), _unit(n, 8)
+    monkeypatch.setenv("PCCM_GRID_COOP", "1")
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    engine.set_normals(0, na); engine.set_normals(1, nb)
+    for d in (0, 1):
+        engine.nn_fuse(d, "row")
+    engine.nn_pair("grid")
+    for d, (q, s, nrm) in enumerate(((a, b, nb), (b, a, na))):
+        idx, d2 = engine.fetch_nn(d)
+        oi, od = orc.nn(q.astype(np.float64), s.astype(np.float64), method="kdtree")
+        assert np.array_equal(d2, od) and np.array_equal(idx, oi), note
+        proj = orc.point_to_plane(q.astype(np.float64), s.astype(np.float64), oi, nrm.astype(np.float64), normal_index="row")
+        assert np.array_equal(engine.point_metric(d, nat.METRIC_PROJ, "row"), proj), note
+        assert same_bits(engine.reduce_total(d, nat.METRIC_D2, "row")[0], np.sum(np.square(proj))), note
+
+
 def test_cloud_pair_report_identical_with_and_without_fusion(monkeypatch):
     rng = np.random.default_rng(13)
     n = 120_000
