@@ -51,15 +51,30 @@ it = fails = 0
 while __name__ == "__main__" and time.time() < t_end:
     rng = np.random.default_rng(seed0 * 1000003 + it)
     it += 1
-    na = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 1000, 4097, 20000, 60000]))
-    nb = int(rng.choice([1, 2, 5, 64, 129, 777, 1000, 8192, 8193, 30000, 50000]))
+    na = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 1000, 4097, 20000, 60000, 150000, 300000]))
+    nb = int(rng.choice([1, 2, 5, 64, 129, 777, 1000, 8192, 8193, 30000, 50000, 160000, 280000]))
     ka, kb = rng.choice(KINDS), rng.choice(KINDS)
     a, b = make(rng, na, ka), make(rng, nb, kb)
     if rng.random() < 0.3:
         b = b + a[rng.integers(0, na)] - b[0]            # make the clouds meet somewhere
     eng = str(rng.choice(["auto", "grid", "grid", "brute"]))
+    if max(na, nb) > 100000 and eng == "brute":
+        eng = "grid"
+    mode = str(rng.choice(["none", "row", "neighbour"]))           # fused projection (round 2)
+    nrm = None
+    if mode != "none":
+        nrm = []
+        for m_ in (na, nb):
+            g_ = rng.standard_normal((m_, 3))
+            g_ /= np.linalg.norm(g_, axis=1, keepdims=True) + 1e-30
+            nrm.append(g_.astype(np.float32).astype(np.float64) if rng.random() < 0.6 else g_)
     try:
         e.set_cloud(0, a); e.set_cloud(1, b)
+        e.nn_want_idx(bool(rng.random() < 0.5))
+        for d in (0, 1):
+            e.nn_fuse(d, None if mode == "none" else mode)
+        if nrm is not None:
+            e.set_normals(0, nrm[0]); e.set_normals(1, nrm[1])
         e.nn_pair(eng)
         e.nn(nat.DIR_SELF, eng)
         for d, (q, r, skip) in enumerate(((a, b, False), (b, a, False), (a, a, True))):
@@ -69,9 +84,15 @@ while __name__ == "__main__" and time.time() < t_end:
             else:
                 oi, od = orc.nn(q, r, skip_same_index=skip, method="kdtree")
                 ok = np.array_equal(d2, od) and np.array_equal(idx, oi)
+            if ok and nrm is not None and d < 2 and (mode == "neighbour" or len(q) <= len(r)):
+                proj = orc.point_to_plane(q, r, oi, nrm[1 - d], normal_index=mode)
+                tot = e.reduce_total(d, nat.METRIC_D2, mode)
+                sq = np.square(proj)
+                ok = (np.float64(tot[0]).tobytes() == np.float64(np.sum(sq)).tobytes() and tot[2] == np.max(sq)
+                      and np.array_equal(e.point_metric(d, nat.METRIC_PROJ, mode), proj))
             if not ok:
                 fails += 1
-                print(f"MISMATCH it={it} seed={seed0} dir={d} eng={eng} A={ka}:{na} B={kb}:{nb}", flush=True)
+                print(f"MISMATCH it={it} seed={seed0} dir={d} eng={eng} mode={mode} A={ka}:{na} B={kb}:{nb}", flush=True)
     except Exception as ex:                               # noqa: BLE001
         fails += 1
         print(f"ERROR it={it} seed={seed0} eng={eng} A={ka}:{na} B={kb}:{nb}: {type(ex).__name__}: {ex}", flush=True)
