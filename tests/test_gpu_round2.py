@@ -92,6 +92,37 @@ def test_normals_in_fp32_words_or_fp64_rows_same_projection(engine, mode):
     assert not np.array_equal(want[(1, "exact")], want[(1, "f64 inexact")])       # the perturbation is visible in the result
 
 
+@pytest.mark.parametrize("want_idx", [False, True])
+def test_reduction_batches_of_every_shape(engine, want_idx):
+    """The reduction kernel is instantiated per shape of a batch (record stride x which fields feed which columns) and falls
+    back to the general kernel for batches whose jobs differ or that reduce the signed projection: D1 alone, D2 alone, both,
+    D1 of one direction with D2 of the other, and the signed projections all equal NumPy on the materialised columns."""
+    rng = np.random.default_rng(41)
+    n, m = 70_000, 66_000
+    a, b = rng.random((n, 3), dtype=np.float32), rng.random((m, 3), dtype=np.float32)
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    engine.set_normals(0, _unit(n, 1)); engine.set_normals(1, _unit(m, 2))
+    engine.nn_want_idx(want_idx)                     # 32- or 16-byte result records
+    for d in (0, 1):
+        engine.nn_fuse(d, "neighbour")
+    cols = {}
+    engine.nn_pair("grid")
+    for d in (0, 1):
+        cols[(d, nat.METRIC_D1)] = engine.fetch_nn(d, want_idx=False)[1]
+        cols[(d, nat.METRIC_D2)] = engine.point_metric(d, nat.METRIC_D2, "neighbour")
+        cols[(d, nat.METRIC_PROJ)] = engine.point_metric(d, nat.METRIC_PROJ, "neighbour")
+    batches = [[(0, nat.METRIC_D1)], [(1, nat.METRIC_D2)], [(0, nat.METRIC_D1), (0, nat.METRIC_D2), (1, nat.METRIC_D1), (1, nat.METRIC_D2)],
+               [(0, nat.METRIC_D1), (1, nat.METRIC_D2)], [(0, nat.METRIC_PROJ), (1, nat.METRIC_PROJ)],
+               [(0, nat.METRIC_D1), (0, nat.METRIC_PROJ)], [(1, nat.METRIC_D1), (1, nat.METRIC_D1)]]
+    for batch in batches:
+        engine.drop_caches(); engine.nn_pair("grid")                       # fresh results, no slot left over
+        got = engine.reduce_total_many(batch, "neighbour")
+        for (d, met), (total, mn, mx) in zip(batch, got):
+            col = cols[(d, met)]
+            assert same_bits(total, np.sum(col)) and mn == np.min(col) and mx == np.max(col), (batch, d, met)
+    engine.nn_want_idx(True)
+
+
 def test_results_without_rows_and_rows_on_demand(engine):
     """pccm_nn_want_idx off: 16-byte result records, identical reductions; the first caller that asks for the matched rows
     gets them from a repeated search of that direction -- same bits as with the rows on from the start."""
