@@ -174,6 +174,15 @@ __device__ __forceinline__ void load_point(const BinJob &J, int64_t i, double &x
     }
 }
 
+// four consecutive rows (row0 + i a multiple of 4) of the fp32 "quads" layout: three 16-byte loads
+__device__ __forceinline__ void load_quad(const BinJob &J, int64_t i, float4 &x, float4 &y, float4 &z)
+{
+    const float4 *q = reinterpret_cast<const float4 *>(J.x32 + ((J.row0 + i) >> 2) * 12);
+    x = q[0];
+    y = q[1];
+    z = q[2];
+}
+
 // tile -> (job, tile of the job); wave-uniform
 __device__ __forceinline__ int tile_job(const BinPlan &P, int64_t &tile)
 {
@@ -200,18 +209,40 @@ __global__ __launch_bounds__(1024) void k_bin_count(BinPlan P, GridGeom g, uint3
     const int jb = tile_job(P, tile);
     const BinJob &J = P.j[jb];
     const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
-    for (int64_t i = i0 + tid; i < i1; i += 4 * nth) {       // four independent rows per trip
-        uint32_t bin[4];
+    if (X32) {
+        // a thread takes whole quads of rows (three 16-byte loads each, every byte of a line used), two quads per trip
+        const int64_t nquad = (i1 - i0 + 3) >> 2;
+        for (int64_t qd = tid; qd < nquad; qd += 2 * nth) {
+            float4 x[2], y[2], z[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t ii = i + nth * k;
-            double x, y, z;
-            load_point<X32>(J, ii < i1 ? ii : i1 - 1, x, y, z);
-            bin[k] = cell_linear(g, x, y, z) >> P.lg;
+            for (int u = 0; u < 2; ++u) {
+                const int64_t q = qd + (int64_t)u * nth;
+                load_quad(J, i0 + 4 * (q < nquad ? q : nquad - 1), x[u], y[u], z[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t i = i0 + 4 * (qd + (int64_t)u * nth);
+                const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w},
+                            zs[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i + k < i1) atomicAdd(&s_hist[cell_linear(g, (double)xs[k], (double)ys[k], (double)zs[k]) >> P.lg], 1u);
+            }
         }
+    } else {
+        for (int64_t i = i0 + tid; i < i1; i += 4 * nth) {       // four independent rows per trip
+            uint32_t bin[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (i + nth * k < i1) atomicAdd(&s_hist[bin[k]], 1u);
+            for (int k = 0; k < 4; ++k) {
+                const int64_t ii = i + nth * k;
+                double x, y, z;
+                load_point<X32>(J, ii < i1 ? ii : i1 - 1, x, y, z);
+                bin[k] = cell_linear(g, x, y, z) >> P.lg;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + nth * k < i1) atomicAdd(&s_hist[bin[k]], 1u);
+        }
     }
     __syncthreads();
     if (CUR) {
@@ -271,6 +302,33 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(BinPlan P, GridGeom g, con
     }
     __syncthreads();
     const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
+    if (X32) {
+        const int64_t nquad = (i1 - i0 + 3) >> 2;
+        for (int64_t qd = tid; qd < nquad; qd += 2 * nth) {
+            float4 x[2], y[2], z[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t q = qd + (int64_t)u * nth;
+                load_quad(J, i0 + 4 * (q < nquad ? q : nquad - 1), x[u], y[u], z[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t i = i0 + 4 * (qd + (int64_t)u * nth);
+                const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w},
+                            zs[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i + k < i1) {
+                        P3 v;
+                        v.x = (double)xs[k]; v.y = (double)ys[k]; v.z = (double)zs[k];
+                        v.row = (int)(J.row0 + i + k);
+                        const uint32_t pos = atomicAdd(&s_cur[cell_linear(g, v.x, v.y, v.z) >> P.lg], 1u);
+                        store_rec(tmp, pos, v);
+                    }
+            }
+        }
+        return;
+    }
     for (int64_t i = i0 + tid; i < i1; i += 4 * nth) {
         P3 v[4];
         uint32_t bin[4];
@@ -430,6 +488,7 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
         const BuildJob &s = jobs.j[k < jobs.njobs ? k : 0];
         BinJob &d = P.j[k];
         d.x64 = s.x64; d.x32 = s.x32; d.row0 = s.row0; d.cs = s.cs;
+        if (rec32 && k < jobs.njobs && (s.row0 & 3)) return fail(PCCM_E_ARG, "a shard must start on a multiple of 4 rows (it starts on 128-row units)");
         d.n = k < jobs.njobs ? s.n : 0;
         // rows per tile: with bin cursors every (tile, bin) costs one returning atomic and one toff word, so larger tiles
         // are cheaper as long as the tiles still fill the chip: 8192 rows -> 60 us per build at 1M + 1M points (4096: 64, 2048: 74)
