@@ -354,9 +354,11 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
                     // two ds_read_b128 (4 LDS cycles each).  Left to itself hipcc drops the unused row words and issues
                     // ds_read_b96, which the LDS serves at 8 cycles per wave (MI355X_MICROARCH.md, LDS table)
                     float4 ca, cb;                                     // (x0 x1 y0 y1), (z0 z1 row0 row1)
+                    // (ABL & 64, timing only: every lane reads the wave's first address -- a broadcast, no bank conflicts)
+                    const uint32_t ar = (ABL & 64) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a) : a;
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(ca), "=&v"(cb)
-                                 : "v"(a)
+                                 : "v"(ar)
                                  : "memory");
                     // both candidates of the slot at once: v_pk_add / v_pk_mul / v_pk_fma_f32
                     const v2f dx = qxx - v2f{ca.x, ca.y}, dy = qyy - v2f{ca.z, ca.w}, dz = qzz - v2f{cb.x, cb.y};
@@ -548,6 +550,7 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
         else if (ablate == 7) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 7>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         else if (ablate == 16) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 16>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         else if (ablate == 32) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 32>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 68) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 68>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         else hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 15>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         return;
     }
