@@ -75,13 +75,7 @@ __device__ __forceinline__ float vmin(float a, float b)      // both finite here
 __device__ __forceinline__ void load_normal(const NNOut &o, int row, double &a, double &b, double &c)
 {
     if (o.nrm32) {
-#ifdef PCCM_NT_NORMALS
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f t_ = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(o.nrm32) + row);
-        const float4 t = make_float4(t_.x, t_.y, t_.z, t_.w);
-#else
         const float4 t = o.nrm32[row];
-#endif
         a = (double)t.x; b = (double)t.y; c = (double)t.z;
     } else {
         const double *np = o.nrm + 3 * (int64_t)row;

@@ -127,14 +127,8 @@ struct NNOut {
 __device__ __forceinline__ void store_result(const NNOut &o, int qrow, double d2, double p, int wrow)
 {
     double *dst = o.rec + (int64_t)(qrow - o.row_base) * o.stride;
-#ifdef PCCM_NT_RESULTS
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    __builtin_nontemporal_store((v2d){d2, p}, reinterpret_cast<v2d *>(dst));
-    if (o.stride == 4) __builtin_nontemporal_store((v2d){__longlong_as_double((long long)(uint32_t)wrow), 0.0}, reinterpret_cast<v2d *>(dst + 2));
-#else
     *reinterpret_cast<double2 *>(dst) = make_double2(d2, p);
     if (o.stride == 4) *reinterpret_cast<double2 *>(dst + 2) = make_double2(__longlong_as_double((long long)(uint32_t)wrow), 0.0);
-#endif
 }
 
 __device__ __forceinline__ void emit_result(const NNOut &o, int qrow, double qx, double qy, double qz, int wrow, double d2,
