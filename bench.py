@@ -296,6 +296,19 @@ def main():
         dist.all_gather_object(allr, mine)
         line["per_rank_kernel_us_per_step"] = allr
 
+    if world > 1 and not args.no_extras:
+        # for the record, next to the contract's strong-scaling figure: the same workload as N INDEPENDENT pairs, one whole pair
+        # per rank and step, no collective in the data path (what sequence.evaluate_pairs does with a codec study's frames)
+        with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine,
+                       use_graph=not args.no_graph) as solo:
+            for _ in range(nwarm):
+                step(solo)
+            dt, _ = timed(lambda: step(solo), args.steps)
+        line["independent_pairs"] = {"ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(world * 2 * n / (dt / args.steps) / 1e6, 2),
+                                     "unit": "Mpoints/s", "scaling": "weak", "pairs_per_step": world,
+                                     "note": "every rank evaluates its own whole pair per step (no sharding, no collective); "
+                                             "time = slowest rank, value = all ranks' points"}
+
     extras = world == 1 and not args.no_extras
     if extras:
         # (1) the full report: the same step plus the self search behind Min/MaxSqrtDistance (options.py:36-37)

@@ -39,6 +39,9 @@ def test_bench_two_gloo_ranks_print_one_valid_line():
     assert [r["rank"] for r in ranks] == [0, 1]
     assert ranks[0]["rows"] == [[0, 300000], [0, 0]] and ranks[1]["rows"] == [[0, 0], [0, 300000]]
     assert all("grid_query" in r and "grid_build" in r for r in ranks)
+    solo = line["independent_pairs"]                                # one whole pair per rank and step, no collective
+    assert solo["scaling"] == "weak" and solo["pairs_per_step"] == 2
+    assert abs(solo["value"] - 2 * 2 * 300000 / (solo["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * solo["value"]
 
 
 NCCL_WORKER = r'''
