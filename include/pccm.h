@@ -114,7 +114,8 @@ int pccm_get_normals(pccm_ctx *ctx, int which, double *out);
 
 /* Query-axis shard of this context: rank r of `world` owns, in every direction, the rows
  * [begin, end) of the iterating cloud returned by pccm_shard_range (boundaries are multiples
- * of 128 rows so that reduction leaves never straddle ranks).  Default: rank 0 of 1. */
+ * of 8192 rows -- whole chunks of NumPy's sum: pccm_reduce_chunks_many -- when the cloud has a chunk for every rank,
+ * else of 128 rows, so that reduction leaves never straddle ranks).  Default: rank 0 of 1. */
 int pccm_set_shard(pccm_ctx *ctx, int rank, int world);
 /* The same per direction: `world` ranks share the rows of direction `dir` and this context is number `rank` of them;
  * world = 0: this context owns NO rows of that direction (another group of ranks searches it) -- its searches and
@@ -188,6 +189,18 @@ int pccm_reduce_total(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
 /* The same for up to 8 columns in one call (out[k][3]): one wait for the GPU and one trip through the FFI per report instead
  * of one per column -- the np.sum / np.max of every GeoMSE / GeoHausdorffDistance row (metric.py:226-228, 366). */
 int pccm_reduce_total_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, double *out);
+
+/* Sharded contexts whose rows start and end on whole 8192-row chunks (pccm_set_shard / pccm_set_shard_dir do that
+ * whenever every rank can have a chunk): the exchange vector shrinks to ONE number per chunk -- NumPy adds the
+ * chunks of a column one after the other, and the GPU has finished each chunk's pairwise tree -- plus the raw values
+ * of the last, partial chunk.  cvecs: the columns' vectors one after the other, pccm_cvec_len(n_iter) doubles each,
+ * zero except for this shard's entries (SUM them over the ranks); minmax[2k], [2k+1]: this shard's extrema of column k.
+ * pccm_finish_chunks() gives np.sum of the whole column from a summed vector.  PCCM_E_STATE when the shard is not
+ * chunk-aligned (then use pccm_reduce / pccm_finish_sum).  Stands under metric.py:226-228, 366 like pccm_reduce. */
+int64_t pccm_cvec_len(int64_t n_iter);
+int pccm_reduce_chunks_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, double *cvecs,
+                            double *minmax);
+int pccm_finish_chunks(const double *cvec, int64_t n_iter, double *sum);
 
 /* Colours of cloud `which` ([n][3] RGB in [0, 1] as Open3D holds them; n = the cloud's point count):
  * replaces np.asarray(cloud.colors) behind get_left/right_colors(), cloud_pair.py:114-118. */

@@ -31,7 +31,7 @@ SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
     "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_want_idx", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
-    "pccm_reduce_total", "pccm_reduce_total_many",
+    "pccm_reduce_total", "pccm_reduce_total_many", "pccm_cvec_len", "pccm_reduce_chunks_many", "pccm_finish_chunks",
     "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
     "pccm_color_transform", "pccm_lzf_decompress", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
     "pccm_sync",
@@ -107,6 +107,10 @@ def load() -> ctypes.CDLL:
     lib.pccm_finish_sum.argtypes = [vp, i64, dp]
     lib.pccm_reduce_total.argtypes = [vp, i32, i32, i32, dp]
     lib.pccm_reduce_total_many.argtypes = [vp, i32, ip, ip, ip, dp]
+    lib.pccm_cvec_len.argtypes = [i64]
+    lib.pccm_cvec_len.restype = i64
+    lib.pccm_reduce_chunks_many.argtypes = [vp, i32, ip, ip, ip, dp, dp]
+    lib.pccm_finish_chunks.argtypes = [vp, i64, dp]
     lib.pccm_sync.argtypes = [vp]
     lib.pccm_drop_caches.argtypes = [vp]
     lib.pccm_color_transform.argtypes = [vp, i64, i32, vp]
@@ -129,7 +133,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_nn_stats.argtypes = [vp, i32, ctypes.POINTER(i64)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("pccm_last_error", "pccm_xvec_len"):
+        if name not in ("pccm_last_error", "pccm_xvec_len", "pccm_cvec_len"):
             fn.restype = i32
     _lib = lib
     return lib
@@ -160,6 +164,20 @@ def device_count() -> int:
 
 def xvec_len(n: int) -> int:
     return int(load().pccm_xvec_len(int(n)))
+
+
+def cvec_len(n: int) -> int:
+    return int(load().pccm_cvec_len(int(n)))
+
+
+def finish_chunks(cvec: np.ndarray, n: int) -> float:
+    """np.sum of the whole per-point column, from its (all-reduced) chunk vector (pccm_reduce_chunks_many)."""
+    cvec = np.ascontiguousarray(cvec, dtype=np.float64)
+    if cvec.shape[0] != cvec_len(n):
+        raise ValueError("chunk vector has the wrong length")
+    out = ctypes.c_double(0.0)
+    _check(load().pccm_finish_chunks(cvec.ctypes.data_as(ctypes.c_void_p), int(n), ctypes.byref(out)))
+    return np.float64(out.value)
 
 
 def finish_sum(xvec: np.ndarray, n: int) -> float:
@@ -477,6 +495,21 @@ class Engine:
         _check(self._lib.pccm_reduce_total_many(self._ctx, k, arr(*[int(r[0]) for r in requests]), arr(*[int(r[1]) for r in requests]),
                                                 arr(*([NORMAL_MODES[normal_mode]] * k)), out))
         return [(np.float64(out[3 * i]), np.float64(out[3 * i + 1]), np.float64(out[3 * i + 2])) for i in range(k)]
+
+    def reduce_chunks_many(self, requests, normal_mode: str = "row"):
+        """-> (one float64 array holding the chunk vectors of up to 8 columns ``(direction, metric)`` one after the other,
+        their lengths, [(min, max)] of this shard) -- see pccm_reduce_chunks_many() in include/pccm.h."""
+        k = len(requests)
+        arr = ctypes.c_int * k
+        lens = [cvec_len(self.n_iter(int(r[0]))) for r in requests]
+        buf = np.empty(sum(lens), dtype=np.float64)
+        mm = (ctypes.c_double * (2 * k))()
+        dp = ctypes.POINTER(ctypes.c_double)
+        _check(self._lib.pccm_reduce_chunks_many(self._ctx, k, arr(*[int(r[0]) for r in requests]), arr(*[int(r[1]) for r in requests]),
+                                                 arr(*([NORMAL_MODES[normal_mode]] * k)), buf.ctypes.data_as(dp), mm))
+        return buf, lens, [(mm[2 * i], mm[2 * i + 1]) for i in range(k)]
+
+    finish_chunks = staticmethod(finish_chunks)
 
     # -- housekeeping -------------------------------------------------------------------------
     def sync(self) -> None:

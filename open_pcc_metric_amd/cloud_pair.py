@@ -386,10 +386,23 @@ class CloudPair:
             if key not in batch:
                 batch.append(key)
             parts, ext = [], []
-            for d, m in batch:
-                xvec, mn, mx = eng.reduce(d, m, self.normal_index)
-                parts.append(xvec)
-                ext += [mx, mn]
+            # shards that start and end on whole 8192-row chunks (every direction of the batch, decided from the row
+            # counts and the plan alone: the same answer on every rank) exchange one number per chunk instead of one per
+            # 128-row leaf -- 20 KB instead of 0.5 MB per report at 1M points
+            chunked = hasattr(eng, "reduce_chunks_many") and len(batch) <= 8 and all(self._chunk_shards(d) for d, _ in batch)
+            if chunked:
+                buf, lens, mms = eng.reduce_chunks_many(batch, self.normal_index)
+                pos = 0
+                for ln, (mn, mx) in zip(lens, mms):
+                    parts.append(buf[pos:pos + ln])
+                    ext += [mx, mn]
+                    pos += ln
+            else:
+                for d, m in batch:
+                    xvec, mn, mx = eng.reduce(d, m, self.normal_index)
+                    parts.append(xvec)
+                    ext += [mx, mn]
+            finish = eng.finish_chunks if chunked else eng.finish_sum
             # the extrema ride along: every rank owns one block of slots and leaves the others zero, so the SUM
             # hands every rank all the local extrema unchanged (x + 0 is exact) -- one collective per report
             slots = np.zeros((coll.world, len(ext)), dtype=np.float64)
@@ -400,10 +413,16 @@ class CloudPair:
             for i, (d, m) in enumerate(batch):
                 n = eng.n_iter(d)
                 ln = len(parts[i])
-                self._xchg[(d, m)] = (eng.finish_sum(summed[pos:pos + ln], n), np.float64(np.min(ext[:, 2 * i + 1])),
+                self._xchg[(d, m)] = (finish(summed[pos:pos + ln], n), np.float64(np.min(ext[:, 2 * i + 1])),
                                       np.float64(np.max(ext[:, 2 * i])))
                 pos += ln
         return self._xchg[key]
+
+    def _chunk_shards(self, direction: int) -> bool:
+        """Do the shards of ``direction`` start and end on 8192-row chunks?  (the rule of pccm_set_shard: whenever the cloud
+        has a chunk for every rank that shares the direction)"""
+        sub_world = max(w for _, w in self._plan[direction])
+        return sub_world >= 1 and self._engine.n_iter(direction) >= sub_world * 8192
 
     def _total(self, direction: int, metric: int):
         """(sum, min, max) of a whole column, unsharded.  The first column a report asks for brings every column the
@@ -621,8 +640,10 @@ def shard_plan(world: int, mode: str = "direction"):
 
 
 def _shard_bounds(n: int, rank: int, world: int):
-    """Rows of an n-row cloud owned by ``rank``: the rule of pccm_set_shard (128-row units); world 0 owns nothing."""
+    """Rows of an n-row cloud owned by ``rank``: the rule of pccm_set_shard (whole 8192-row chunks of NumPy's sum when every
+    rank can have one, else 128-row leaves); world 0 owns nothing."""
     if world <= 0:
         return 0, 0
-    units = (n + 127) // 128
-    return min(n, units * rank // world * 128), min(n, units * (rank + 1) // world * 128)
+    unit = 8192 if n >= world * 8192 else 128
+    units = (n + unit - 1) // unit
+    return min(n, units * rank // world * unit), min(n, units * (rank + 1) // world * unit)

@@ -149,9 +149,12 @@ static void shard_of(int64_t n, int rank, int world, int64_t *b, int64_t *e)
         *e = 0;
         return;
     }
-    const int64_t units = (n + kLeaf - 1) / kLeaf;
+    // shards start on whole 8192-row chunks of NumPy's sum whenever every rank can have one (the ranks then exchange
+    // one number per chunk: pccm_reduce_chunks_many), else on 128-row leaves (pccm_reduce's per-leaf exchange vector)
+    const int64_t unit = n >= (int64_t)world * kChunk ? kChunk : kLeaf;
+    const int64_t units = (n + unit - 1) / unit;
     int64_t u0 = units * rank / world, u1 = units * (rank + 1) / world;
-    int64_t lo = u0 * kLeaf, hi = u1 * kLeaf;
+    int64_t lo = u0 * unit, hi = u1 * unit;
     *b = lo < n ? lo : n;
     *e = hi < n ? hi : n;
 }
@@ -1216,6 +1219,82 @@ static int total_from_slot(pccm_ctx *ctx, int dir, int metric, int normal_mode, 
     out[0] = total;
     out[1] = mn;
     out[2] = mx;
+    return PCCM_OK;
+}
+
+int64_t pccm_cvec_len(int64_t n_iter)
+{
+    if (n_iter <= 0) return 0;
+    return n_iter / kChunk + n_iter % kChunk;
+}
+
+// one column's chunk vector from its slot: a number per full 8192-row chunk this shard owns (the GPU finished both
+// halves of the chunk's pairwise tree) + the raw values of the last, partial chunk; zero elsewhere
+static int chunks_from_slot(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *cvec, double minmax[2])
+{
+    if (dir < 0 || dir > 2) return fail(PCCM_E_ARG, "bad direction %d", dir);
+    ReduceSlot *s = slot_find(ctx, dir, metric, normal_mode);
+    if (!s) {
+        int rc = prefetch_many(ctx, 1, &dir, &metric, &normal_mode, false);
+        if (rc) return rc;
+        s = slot_find(ctx, dir, metric, normal_mode);
+        if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
+    }
+    if (s->wait_ev) PCCM_HIP(hipEventSynchronize(s->wait_ev));
+    s->pending = false;
+    const int64_t n = s->n_iter, nunits = s->nunits, nblocks = s->nblocks;
+    const int64_t nfull = n / kChunk, full_rows = nfull * kChunk;
+    memset(cvec, 0, (size_t)pccm_cvec_len(n) * sizeof(double));
+    minmax[0] = INFINITY;
+    minmax[1] = -INFINITY;
+    if (s->end <= s->begin) return PCCM_OK;                  // this rank owns no rows of the direction
+    if (s->begin % kChunk != 0 || (s->end % kChunk != 0 && s->end != n))
+        return fail(PCCM_E_STATE, "rows [%lld, %lld) do not start and end on 8192-row chunks: use pccm_reduce", (long long)s->begin,
+                    (long long)s->end);
+    const double *bsum = s->host + 3 * nunits, *bmin = bsum + nblocks, *bmax = bsum + 2 * nblocks;
+    const int64_t c0 = s->begin / kChunk;
+    const int64_t owned = ((s->end < full_rows ? s->end : full_rows) - s->begin) / kChunk;
+    for (int64_t c = 0; c < owned; ++c) cvec[c0 + c] = bsum[2 * c] + bsum[2 * c + 1];
+    if (s->tail_n > 0)
+        memcpy(cvec + nfull + (s->t0 - full_rows), s->host + 3 * nunits + 3 * nblocks, (size_t)s->tail_n * sizeof(double));
+    for (int64_t b = 0; b < nblocks; ++b) {
+        minmax[0] = bmin[b] < minmax[0] ? bmin[b] : minmax[0];
+        minmax[1] = bmax[b] > minmax[1] ? bmax[b] : minmax[1];
+    }
+    return PCCM_OK;
+}
+
+int pccm_reduce_chunks_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, double *cvecs, double *minmax)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (n < 0 || n > 8 || (n > 0 && (!dirs || !metrics || !normal_modes || !cvecs || !minmax))) return fail(PCCM_E_ARG, "1..8 requests expected");
+    int rc = prefetch_many(ctx, n, dirs, metrics, normal_modes, false);       // whatever is not enqueued yet, in one batch
+    if (rc) return rc;
+    for (int k = 0; k < n; ++k) {
+        const Cloud *it, *se;
+        if ((rc = dir_clouds(ctx, dirs[k], &it, &se))) return rc;
+        if ((rc = chunks_from_slot(ctx, dirs[k], metrics[k], normal_modes[k], cvecs, minmax + 2 * k))) return rc;
+        cvecs += pccm_cvec_len(it->n);
+    }
+    return PCCM_OK;
+}
+
+int pccm_finish_chunks(const double *cvec, int64_t n_iter, double *sum)
+{
+    if (!cvec || !sum || n_iter < 0) return fail(PCCM_E_ARG, "bad argument");
+    const int64_t nfull = n_iter / kChunk, tail = n_iter % kChunk;
+    double s = 0.0;
+    bool first = true;
+    for (int64_t c = 0; c < nfull; ++c) {                    // np.sum: the chunks one after the other
+        s = first ? cvec[c] : s + cvec[c];
+        first = false;
+    }
+    if (tail) {
+        const double ts = np_pairwise_sum(cvec + nfull, tail);
+        s = first ? ts : s + ts;
+    }
+    *sum = s;
     return PCCM_OK;
 }
 

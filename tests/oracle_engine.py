@@ -107,10 +107,8 @@ class OracleEngine:
     def shard_range(self, d):
         n = self.n_iter(d)
         rank, world = self.dir_shard.get(d, (self.rank, self.world))
-        if world <= 0:
-            return 0, 0
-        units = (n + 127) // 128
-        return min(n, units * rank // world * 128), min(n, units * (rank + 1) // world * 128)
+        from open_pcc_metric_amd.cloud_pair import _shard_bounds        # the library's rule (chunks when possible, else leaves)
+        return _shard_bounds(n, rank, world)
 
     def _clouds(self, d):
         return {nat.DIR_LEFT: (0, 1), nat.DIR_RIGHT: (1, 0), nat.DIR_SELF: (0, 0)}[d]
@@ -180,6 +178,39 @@ class OracleEngine:
         return xvec, mn, mx
 
     finish_sum = staticmethod(nat.finish_sum)
+
+    def reduce_chunks_many(self, requests, normal_mode="row"):
+        """pccm_reduce_chunks_many: one number per owned 8192-row chunk (np.sum of the chunk = NumPy's pairwise tree over it)
+        + the raw values of the partial last chunk."""
+        bufs, lens, mms = [], [], []
+        for d, metric in requests:
+            col = self.point_metric(d, metric, normal_mode)
+            n = self.n_iter(d)
+            b, e = self.shard_range(d)
+            nfull, tail = n // 8192, n % 8192
+            cvec = np.zeros(nfull + tail)
+            if e > b:
+                assert b % 8192 == 0 and (e % 8192 == 0 or e == n), "shard is not chunk-aligned"
+                for row in range(b, min(e, nfull * 8192), 8192):
+                    cvec[row // 8192] = np.sum(col[row - b:row - b + 8192])
+                t0 = max(b, nfull * 8192)
+                if t0 < e:
+                    cvec[nfull + (t0 - nfull * 8192):nfull + (e - nfull * 8192)] = col[t0 - b:]
+            bufs.append(cvec); lens.append(len(cvec))
+            mms.append((np.min(col) if len(col) else np.inf, np.max(col) if len(col) else -np.inf))
+            self.calls.append(("reduce_chunks", d, metric))
+        return np.concatenate(bufs) if bufs else np.zeros(0), lens, mms
+
+    @staticmethod
+    def finish_chunks(cvec, n):
+        nfull = n // 8192
+        s = None
+        for c in range(nfull):
+            s = cvec[c] if s is None else s + cvec[c]
+        if n % 8192:
+            ts = np.sum(np.ascontiguousarray(cvec[nfull:]))
+            s = ts if s is None else s + ts
+        return np.float64(0.0 if s is None else s)
 
     def sync(self):
         pass

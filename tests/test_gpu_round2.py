@@ -202,6 +202,49 @@ def test_per_direction_shards_at_the_c_abi(engine):
         assert np.array_equal(acc[d][2], xvec) and acc[d][3] == mn and acc[d][4] == mx
 
 
+def test_chunk_vectors_of_four_ranks_give_the_unsharded_sums(engine):
+    """pccm_reduce_chunks_many / pccm_finish_chunks: shards of clouds with a chunk for every rank start on 8192-row chunks,
+    and the ranks' chunk vectors (one number per chunk + the raw tail), summed, finish to np.sum of the whole column --
+    bit for bit, for D1 and D2 of both directions in one call."""
+    rng = np.random.default_rng(12)
+    n, m = 70_000, 45_111
+    a, b = rng.random((n, 3), dtype=np.float32), rng.random((m, 3), dtype=np.float32)
+    engine.set_cloud(0, a); engine.set_cloud(1, b)
+    engine.set_normals(0, _unit(n, 1)); engine.set_normals(1, _unit(m, 2))
+    for d in (0, 1):
+        engine.nn_fuse(d, "neighbour")
+    engine.nn_pair("grid")
+    reqs = [(0, nat.METRIC_D1), (0, nat.METRIC_D2), (1, nat.METRIC_D1), (1, nat.METRIC_D2)]
+    want = engine.reduce_total_many(reqs, "neighbour")
+    world = 4
+    acc, lens, mins, maxs = None, None, [np.inf] * 4, [-np.inf] * 4
+    for rank in range(world):
+        engine.set_shard(rank, world)
+        for d in (0, 1):
+            b0, e0 = engine.shard_range(d)
+            assert b0 % 8192 == 0 and (e0 % 8192 == 0 or e0 == (n if d == 0 else m))
+        engine.drop_caches(); engine.nn_pair("grid")
+        buf, lens, mms = engine.reduce_chunks_many(reqs, "neighbour")
+        acc = buf.copy() if acc is None else acc + buf
+        mins = [min(x, mm[0]) for x, mm in zip(mins, mms)]
+        maxs = [max(x, mm[1]) for x, mm in zip(maxs, mms)]
+    engine.set_shard(0, 1)
+    assert lens == [nat.cvec_len(n)] * 2 + [nat.cvec_len(m)] * 2 and nat.cvec_len(n) == n // 8192 + n % 8192
+    pos = 0
+    for k, ((d, _), ln) in enumerate(zip(reqs, lens)):
+        total = engine.finish_chunks(acc[pos:pos + ln], n if d == 0 else m)
+        assert same_bits(total, want[k][0]) and mins[k] == want[k][1] and maxs[k] == want[k][2]
+        pos += ln
+    engine.set_shard(0, 3)                                   # 45 111 rows have no chunk for each of 6 ranks: 128-row leaves
+    engine.set_shard(5, 6)
+    b0, e0 = engine.shard_range(1)
+    assert b0 % 128 == 0 and b0 % 8192 != 0
+    engine.drop_caches(); engine.nn_pair("grid")
+    with pytest.raises(nat.PccmStateError):
+        engine.reduce_chunks_many([(1, nat.METRIC_D1)], "neighbour")
+    engine.set_shard(0, 1)
+
+
 def test_clumped_bricks_and_leftovers_stay_exact(engine, monkeypatch):
     """The LDS-brick kernel hands bricks that exceed its LDS budget to the general kernels and loops over leftover queries
     when a brick holds more than a workgroup: a dense clump inside uniform data exercises both."""

@@ -53,7 +53,8 @@ col = np.asarray(pair.get_right_neighbour_distances())          # all-gathered c
 ev = np.asarray(pair.get_left_error_vector())
 out = {"rank": dist.get_rank(), "shard": pair._engine.shard_range(0), "shards": [pair._engine.shard_range(d) for d in (0, 1, 2)],
        "rows": [[list(map(str, k)), [float(x).hex() for x in np.atleast_1d(v)]] for k, v in res.items()],
-       "col_sum": float(np.sum(col)).hex(), "col_len": len(col), "ev_sum": float(np.sum(ev)).hex()}
+       "col_sum": float(np.sum(col)).hex(), "col_len": len(col), "ev_sum": float(np.sum(ev)).hex(),
+       "calls": sorted(set(c[0] for c in pair._engine.calls if c[0].startswith("reduce")))}
 with open(os.path.join(os.environ["PCCM_OUT"], f"rank{dist.get_rank()}.json"), "w") as fh:
     json.dump(out, fh)
 dist.destroy_process_group()
@@ -61,7 +62,7 @@ dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("n,world,mode", [(1000, 2, "direction"), (20011, 2, "direction"), (20011, 4, "direction"),
-                                          (20011, 8, "direction"), (5000, 3, "direction"), (20011, 2, "rows")])
+                                          (20011, 8, "direction"), (5000, 3, "direction"), (20011, 2, "rows"), (40000, 4, "rows")])
 def test_gloo_ranks_match_single_process(tmp_path, n, world, mode):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from open_pcc_metric_amd.calculator import MetricCalculator
@@ -84,6 +85,13 @@ def test_gloo_ranks_match_single_process(tmp_path, n, world, mode):
         owned = [tuple(o["shards"][d]) for o in outs if o["shards"][d][1] > o["shards"][d][0]]
         assert owned[0][0] == 0 and owned[-1][1] == n_iter
         assert all(a[1] == b[0] and a[1] % 128 == 0 for a, b in zip(owned, owned[1:]))
+    # the exchange: one number per 8192-row chunk when every rank that shares a direction can own whole chunks (then the
+    # shards start on chunk boundaries), else one per 128-row leaf -- the same choice on every rank
+    sub = world if mode == "rows" else (world + 1) // 2
+    want_calls = ["reduce_chunks"] if n >= sub * 8192 else ["reduce"]
+    assert all(o["calls"] == want_calls for o in outs), [o["calls"] for o in outs]
+    if want_calls == ["reduce_chunks"]:
+        assert all(sh[0] % 8192 == 0 for o in outs for sh in o["shards"])
     if mode == "direction":
         # the split is by direction first: no rank owns rows of both the left and the right direction
         assert all(not (o["shards"][0][1] > o["shards"][0][0] and o["shards"][1][1] > o["shards"][1][0]) for o in outs)
