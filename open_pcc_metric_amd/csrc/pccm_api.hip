@@ -1059,8 +1059,17 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
 int pccm_reduce_prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes)
 {
     CHECK_CTX(ctx);
-    // per-leaf results cross PCIe only when a sharded exchange will need them
-    return prefetch_many(ctx, n, dirs, metrics, normal_modes, ctx->sharded());
+    // per-leaf results cross PCIe only when a sharded exchange will need them: shards that start and end on whole chunks
+    // exchange chunk sums (pccm_reduce_chunks_many), which the block results already hold
+    bool units = false;
+    if (ctx->sharded() && dirs)
+        for (int k = 0; k < n && !units; ++k) {
+            if (dirs[k] < 0 || dirs[k] > 2) continue;                 // reported by prefetch_many
+            const NNResult &res = ctx->nn[dirs[k]];
+            const Cloud &it = ctx->cloud[dirs[k] == PCCM_DIR_RIGHT ? 1 : 0];
+            units = res.end > res.begin && (res.begin % kChunk != 0 || (res.end % kChunk != 0 && res.end != it.n));
+        }
+    return prefetch_many(ctx, n, dirs, metrics, normal_modes, units);
 }
 
 static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, bool want_units)
