@@ -68,6 +68,41 @@ while __name__ == "__main__" and time.time() < t_end:
             g_ = rng.standard_normal((m_, 3))
             g_ /= np.linalg.norm(g_, axis=1, keepdims=True) + 1e-30
             nrm.append(g_.astype(np.float32).astype(np.float64) if rng.random() < 0.6 else g_)
+    world = int(rng.choice([1, 1, 2, 3, 4, 5]))                      # sharded contexts, one "rank" after the other (round 2)
+    if world > 1:
+        try:
+            e.set_cloud(0, a); e.set_cloud(1, b)
+            e.nn_want_idx(bool(rng.random() < 0.5))
+            for d in (0, 1):
+                e.nn_fuse(d, None)
+            pieces = {0: [], 1: []}
+            vec = {0: None, 1: None}
+            chunked = {d: (na if d == 0 else nb) >= world * 8192 for d in (0, 1)}
+            for rank in range(world):
+                e.set_shard(rank, world)
+                e.drop_caches(); e.nn_pair("grid" if eng == "brute" else eng)
+                for d in (0, 1):
+                    pieces[d].append(e.fetch_nn(d))
+                    if chunked[d]:
+                        buf, lens, mms = e.reduce_chunks_many([(d, nat.METRIC_D1)], "row")
+                    else:
+                        buf = e.reduce(d, nat.METRIC_D1, "row")[0]
+                    vec[d] = buf.copy() if vec[d] is None else vec[d] + buf
+            e.set_shard(0, 1)
+            for d, (q, r) in enumerate(((a, b), (b, a))):
+                oi, od = orc.nn(q, r, method="kdtree")
+                idx = np.concatenate([p_[0] for p_ in pieces[d]]); d2 = np.concatenate([p_[1] for p_ in pieces[d]])
+                tot = (e.finish_chunks if chunked[d] else e.finish_sum)(vec[d], len(q))
+                if not (np.array_equal(d2, od) and np.array_equal(idx, oi) and np.float64(tot).tobytes() == np.float64(np.sum(od)).tobytes()):
+                    fails += 1
+                    print(f"MISMATCH (sharded x{world}) it={it} seed={seed0} dir={d} eng={eng} A={ka}:{na} B={kb}:{nb}", flush=True)
+        except Exception as ex:                               # noqa: BLE001
+            fails += 1
+            e.set_shard(0, 1)
+            print(f"ERROR (sharded x{world}) it={it} seed={seed0} eng={eng} A={ka}:{na} B={kb}:{nb}: {type(ex).__name__}: {ex}", flush=True)
+        if it % 50 == 0:
+            print(f"... {it} cases, {fails} failures", flush=True)
+        continue
     try:
         e.set_cloud(0, a); e.set_cloud(1, b)
         e.nn_want_idx(bool(rng.random() < 0.5))
