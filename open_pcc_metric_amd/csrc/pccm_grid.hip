@@ -822,7 +822,18 @@ static bool pair_rec32(const pccm_ctx *ctx)
 
 // (re)build the combined grid when either cloud changed, the caches were dropped or the record layout asked for
 // differs from the built one (need64: a caller that reads GridRec records, pccm_normals.hip)
-static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, uint32_t *zero = nullptr, int nzero = 0, bool *rebuilt = nullptr)
+// A shard's rows of the iterating cloud that want the same cell sort as the grid being built: when exactly one cloud is
+// (re)built, they ride along as the second job of the same three launches instead of paying three more
+struct ShardSort {
+    const Cloud *it = nullptr;
+    int64_t begin = 0, n = 0;
+    bool done = false;
+    const char *recs = nullptr;        // where the shard's cell-sorted records went
+    const uint32_t *cs = nullptr;      // ... and their cell starts
+};
+
+static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, uint32_t *zero = nullptr, int nzero = 0, bool *rebuilt = nullptr,
+                       ShardSort *shard = nullptr)
 {
     if (rebuilt) *rebuilt = false;
     Grid &gr = ctx->grid;
@@ -856,6 +867,17 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
         jobs.total += c.n;
     }
     if (jobs.njobs == 1) jobs.j[1] = jobs.j[0];
+    if (shard && shard->n > 0 && jobs.njobs == 1 && jobs.total > 0 && rec32 &&
+        (size_t)(first - (char *)gr.recs.p) + (size_t)(jobs.total + shard->n) * rsz <= gr.recs.bytes) {
+        // (16-byte records fill half of the buffer that is sized for either layout: the shard's records fit behind the cloud's)
+        if ((rc = ensure(ctx, ctx->g_hist, (size_t)3 * (ncells + 1) * sizeof(uint32_t)))) return rc;
+        jobs.j[1] = {shard->it->xyz64, (const float *)shard->it->xyz32, shard->begin, shard->n, (uint32_t *)ctx->g_hist.p};
+        jobs.njobs = 2;
+        shard->recs = first + (size_t)jobs.total * rsz;
+        shard->cs = (const uint32_t *)ctx->g_hist.p;
+        jobs.total += shard->n;
+        shard->done = true;
+    }
     if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, ncells, first, rec32, zero, nzero))) return rc;
     if (rebuilt) *rebuilt = jobs.total > 0;
     for (int a = 0; a < 3; ++a) {
@@ -1018,7 +1040,23 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
     }
     const bool side_by_side = ndirs > 0 && dhi - dlo + 1 == ndirs;
     bool rebuilt = false;
-    if ((rc = ensure_grid(ctx, false, need, side_by_side ? (uint32_t *)ctx->counters.p + 2 * dlo : nullptr, 2 * ndirs, &rebuilt))) return rc;
+    // a single sharded direction of this call (the direction-first split): its rows are cell-sorted by the grid build itself
+    ShardSort ride;
+    int ride_dir = -1, nsh = 0;
+    for (int d = 0; d < ndirs; ++d) {
+        const NNResult &res = ctx->nn[dirs[d]];
+        const Cloud &it = ctx->cloud[dirs[d] == PCCM_DIR_RIGHT ? 1 : 0];
+        if (res.end > res.begin && !(res.begin == 0 && res.end == it.n)) {
+            ++nsh;
+            ride_dir = dirs[d];
+            ride.it = &it;
+            ride.begin = res.begin;
+            ride.n = res.end - res.begin;
+        }
+    }
+    if (nsh != 1) ride_dir = -1;
+    if ((rc = ensure_grid(ctx, false, need, side_by_side ? (uint32_t *)ctx->counters.p + 2 * dlo : nullptr, 2 * ndirs, &rebuilt,
+                          ride_dir >= 0 ? &ride : nullptr))) return rc;
     const Grid &gr = ctx->grid;
     const GridGeom g = geom_of(gr);
     const uint32_t *cs_all = (const uint32_t *)gr.cell_start.p;
@@ -1095,7 +1133,13 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         res.stats[1] = gr.ncells;       // pccm_nn_stats: the grid this search ran on (the bench's byte count needs it)
         res.stats[2] = 0;
     }
-    if (nshard > 0) {
+    if (nshard == 1 && ride_dir == shard_dirs[0] && ride.done) {
+        QueryJobs &dst = (ride_dir == PCCM_DIR_SELF) ? selfj : normal;
+        QueryJob &J = dst.j[job_of_dir[ride_dir]];
+        J.qrecs = ride.recs;
+        J.qbase = J.qrecs;                                           // cell starts are relative to the shard's first record
+        J.qcs = ride.cs;
+    } else if (nshard > 0) {
         // cell-sort the shards' rows: up to two directions per counting sort (same launches as a grid build); every
         // shard keeps its own cell starts (the brick kernel finds a brick's queries through them)
         ProfScope ps(ctx, PCCM_K_GRID_BUILD);

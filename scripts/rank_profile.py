@@ -26,15 +26,22 @@ def one_rank(eng, plan, rank, steps=10):
     sharded = any(plan[d][rank] != (0, 1) for d in (0, 1, 2))
     reqs = [(d, m) for d in (0, 1) for m in (nat.METRIC_D1, nat.METRIC_D2) if eng.shard_range(d)[1] > eng.shard_range(d)[0]]
 
+    def aligned(d):
+        b, e = eng.shard_range(d)
+        return b % 8192 == 0 and (e % 8192 == 0 or e == eng.n_iter(d))
+    chunked = all(aligned(d) for d, _ in reqs)
+
     def step():
         eng.drop_caches()
         eng.nn_pair("grid")
         eng.reduce_prefetch_many(reqs, "row")
-        for d, m in reqs:
-            if sharded:
+        if not sharded:
+            eng.reduce_total_many(reqs, "row")
+        elif chunked:
+            eng.reduce_chunks_many(reqs, "row")        # one number per 8192-row chunk for the exchange (what CloudPair does)
+        else:
+            for d, m in reqs:
                 eng.reduce(d, m, "row")                # per-leaf sums for the exchange vector
-            else:
-                eng.reduce_total(d, m, "row")
     for _ in range(3):
         step()
     eng.profile(True)
