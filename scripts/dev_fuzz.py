@@ -78,17 +78,27 @@ while __name__ == "__main__" and time.time() < t_end:
             pieces = {0: [], 1: []}
             vec = {0: None, 1: None}
             chunked = {d: (na if d == 0 else nb) >= world * 8192 for d in (0, 1)}
+            from open_pcc_metric_amd.cloud_pair import shard_plan
+            mode_s = str(rng.choice(["rows", "direction"]))
+            plan = shard_plan(world, mode_s)
+            sub = {d: max(w_ for _, w_ in plan[d]) for d in (0, 1)}
+            chunked = {d: (na if d == 0 else nb) >= sub[d] * 8192 for d in (0, 1)}
             for rank in range(world):
-                e.set_shard(rank, world)
+                for d in (0, 1, 2):
+                    e.set_shard_dir(d, *plan[d][rank])
                 e.drop_caches(); e.nn_pair("grid" if eng == "brute" else eng)
                 for d in (0, 1):
+                    b0, e0 = e.shard_range(d)
+                    if e0 <= b0:
+                        continue
                     pieces[d].append(e.fetch_nn(d))
                     if chunked[d]:
                         buf, lens, mms = e.reduce_chunks_many([(d, nat.METRIC_D1)], "row")
                     else:
                         buf = e.reduce(d, nat.METRIC_D1, "row")[0]
                     vec[d] = buf.copy() if vec[d] is None else vec[d] + buf
-            e.set_shard(0, 1)
+            for d in (0, 1, 2):
+                e.set_shard_dir(d, 0, 1)
             for d, (q, r) in enumerate(((a, b), (b, a))):
                 oi, od = orc.nn(q, r, method="kdtree")
                 idx = np.concatenate([p_[0] for p_ in pieces[d]]); d2 = np.concatenate([p_[1] for p_ in pieces[d]])
@@ -98,7 +108,8 @@ while __name__ == "__main__" and time.time() < t_end:
                     print(f"MISMATCH (sharded x{world}) it={it} seed={seed0} dir={d} eng={eng} A={ka}:{na} B={kb}:{nb}", flush=True)
         except Exception as ex:                               # noqa: BLE001
             fails += 1
-            e.set_shard(0, 1)
+            for d in (0, 1, 2):
+                e.set_shard_dir(d, 0, 1)
             print(f"ERROR (sharded x{world}) it={it} seed={seed0} eng={eng} A={ka}:{na} B={kb}:{nb}: {type(ex).__name__}: {ex}", flush=True)
         if it % 50 == 0:
             print(f"... {it} cases, {fails} failures", flush=True)
