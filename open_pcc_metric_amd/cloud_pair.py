@@ -132,7 +132,7 @@ class DeviceColumn(_DeviceArray):
         """(sum, min, max) of the whole column: fused on the GPU, exchanged across ranks."""
         if self._red is None:
             p = self._pair
-            if not p._coll.sharded and hasattr(p._engine, "reduce_total"):
+            if p._fast_totals:                            # unsharded, engine with pccm_reduce_total: the usual case
                 total, mn, mx = p._total(self._dir, self._METRIC[self._kind])
             elif p._coll.sharded:
                 total, mn, mx = p._sharded_reduction(self._dir, self._METRIC[self._kind])
@@ -269,6 +269,7 @@ class CloudPair:
             self._owns_engine = True
             self._coll.device = device            # the nccl exchange is staged on the same GPU
         self._engine = _engine
+        self._fast_totals = not self._coll.sharded and hasattr(_engine, "reduce_total")   # whole columns finished by one call
         for k, cloud in enumerate(self.clouds):
             _engine.set_cloud(k, cloud.points)
             if _has_normals(cloud):
@@ -428,7 +429,10 @@ class CloudPair:
         """(sum, min, max) of a whole column, unsharded.  The first column a report asks for brings every column the
         report enqueued (prefetch_reductions) back in ONE call: one wait for the GPU, one trip through ctypes."""
         key = (direction, metric)
-        if key not in self._totals:
+        done = self._totals.get(key)
+        if done is not None:
+            return done
+        if True:
             eng = self._engine
             batch = [k for k in self._xchg_wanted if k not in self._totals]
             if key not in batch:

@@ -352,8 +352,14 @@ class SymmetricMetric(SecondaryMetric):                          # metric.py:446
     def calculate(self, lmetric: AbstractMetric, rmetric: AbstractMetric) -> None:
         # quality-like metrics (PSNR) report the worse = smaller side, error-like the larger;
         # the left value wins ties in both cases (Python's min/max keep the first extreme).
-        pick = min if self.is_proportional else max
-        self.value = pick([lmetric.value, rmetric.value], key=_norm)
+        # (written out: min / max keep the first extreme, i.e. the right value replaces the left one only when it is strictly
+        # smaller / larger -- with NaN keys nothing is, exactly as min([l, r], key=...) behaves)
+        left, right = lmetric.value, rmetric.value
+        kl, kr = _norm(left), _norm(right)
+        if self.is_proportional:
+            self.value = right if kr < kl else left
+        else:
+            self.value = right if kr > kl else left
 
 
 def _norm(value):
