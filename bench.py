@@ -108,6 +108,22 @@ def committed_traffic(kernel, n, world):
     return None, "no PMC profile committed for this engine/size"
 
 
+def self_launch(nproc):
+    """Run this same command line under torch.distributed.run with one rank per GPU (what the driver's launch line does) and
+    pass its output through.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +138,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (never an exec), before
+        # anything in this process has touched HIP or torch.cuda; relay rank 0's JSON line and the child's return code
+        sys.exit(self_launch(args.gpus))
 
     lib = os.path.join(ROOT, "open_pcc_metric_amd", "csrc", "libpccm.so")
     if not os.path.exists(lib) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -150,9 +171,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+        args.gpus = world                         # a launcher's world size wins over the flag
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: open_pcc_metric_amd has no CPU path")
     local = local % torch.cuda.device_count()
@@ -283,6 +302,7 @@ def main():
                    "hip_graph": not args.no_graph,
                    "fallback_queries": [s["fallback_queries"] for s in stats],
                    ("grid_cells" if gq_n else "scan_splits"): [s["splits"] for s in stats]},
+        "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (args.backend if world > 1 else None),
         "roofline": roofline, "roofline_measured_by": prof_leg,
         "kernel_us_per_step": {k: round(v[0] / prof_steps * 1e3, 1) for k, v in prof.items() if v[1]},
         "result_sample": {"GeoMSE_sym_d1": float(result[("SymmetricMetric", "GeoMSE", True, False, "GeoMSE", False, False)]),

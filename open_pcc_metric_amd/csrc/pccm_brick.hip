@@ -16,7 +16,7 @@
 //      cell-sorted order, so the lanes of a wave sit in neighbouring cells of one x-row and their LDS reads broadcast
 //      or fall on consecutive banks; per query nine x-runs of three cells each are scanned slot by slot: two
 //      ds_read_b128, six packed-fp32 instructions for both candidates, (best, second best, address of the best)
-//      tracked per candidate -- 17 VALU instructions per pair.  A slot may bring a record of a neighbouring cell
+//      tracked per slot -- 15 VALU instructions per pair of candidates.  A slot may bring a record of a neighbouring cell
 //      along: a real point that can only lose, so no per-candidate range test exists,
 //   4. certification as in pccm_brute.hip K2 -- the fp32 winner is the unique fp64 winner when the second best
 //      d32 lies above thr(best), evaluated in fp32 with a conservative margin -- then the exact fp64 d2 from the
@@ -47,7 +47,6 @@ struct BrickParams {
     int bx;                 // cells per brick along x
     int nbx, nby, nbz;      // bricks per axis
     int64_t per_job;        // nbx * nby * nbz
-    uint32_t m_nbx, m_nby;  // floor(2^32 / d) + 1 for d = nbx, nby: brick -> (x, y, z) by multiply-high on the scalar unit (0: divide)
     uint32_t total;         // bricks of all jobs
     int cap;                // staged records that fit (< 65536: LDS positions are kept as uint16)
     unsigned long long *stamps;   // diagnostic build only (PCCM_BRICK_STAMP=1): per-phase wave-cycle sums, else null
@@ -110,11 +109,11 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
     if (vb >= bp.per_job) return;
     const QueryJob &J = jobs.j[jb];
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
-    // brick -> (x, y, z): n / d = mulhi(n, floor(2^32 / d) + 1) exactly while n d < 2^32 (the host checks); the 64-bit
-    // divisions this replaces were 360 scalar and 50 vector instructions per wave
+    // brick -> (x, y, z): two 32-bit divisions on wave-uniform values (the 64-bit ones they replace were 360 scalar and 50
+    // vector instructions per wave)
     const uint32_t vbu = (uint32_t)vb;
-    const uint32_t t_xy = bp.m_nbx ? (bp.nbx == 1 ? vbu : __umulhi(vbu, bp.m_nbx)) : vbu / (uint32_t)bp.nbx;
-    const uint32_t t_z = bp.m_nby ? (bp.nby == 1 ? t_xy : __umulhi(t_xy, bp.m_nby)) : t_xy / (uint32_t)bp.nby;
+    const uint32_t t_xy = vbu / (uint32_t)bp.nbx;
+    const uint32_t t_z = t_xy / (uint32_t)bp.nby;
     const int ibx = (int)(vbu - t_xy * (uint32_t)bp.nbx), iby = (int)(t_xy - t_z * (uint32_t)bp.nby), ibz = (int)t_z;
     const int bx0 = ibx * bp.bx, bx1 = min(bx0 + bp.bx, dimx);
     const int by0 = iby * BY, bz0 = ibz * BZ;
@@ -504,7 +503,11 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     static const int cap_env = [] { const char *e = getenv("PCCM_BRICK_CAP"); return e ? atoi(e) : 0; }();
     if (cap_env > 0) cap = cap_env;
     if (cap < 256) cap = 256;
-    if (cap > 3800) cap = 3800;                         // 60 KB of records: static + dynamic LDS stay under 64 KB
+    // static + dynamic LDS of one workgroup stay under 64 KB: the statics are s_lcs (kNRun x kLcsPitch uint16) and five
+    // run / row tables -- 3.6 KB for the 4 x 2 shape, 5.5 KB for 4 x 4
+    constexpr int kStatic = (BY + 2) * (BZ + 2) * (kLcsPitch * 2 + 12) + (BY * BZ) * 8 + 64;
+    const int cap_max = (64 * 1024 - kStatic) / (int)sizeof(float4) - 2;
+    if (cap > cap_max) cap = cap_max;
     bp.cap = cap;
     // workgroup size: the queries a brick is expected to hold plus 2.5 sigma (Poisson), in whole waves -- but never
     // so large that the workgroups the LDS admits per CU exceed the CU's 32 wave slots (occupancy is what hides the
@@ -521,8 +524,9 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     const size_t lds = (size_t)(bp.cap + 2) * sizeof(float4);
     bp.total = (uint32_t)(bp.per_job * jobs.njobs);
     dim3 grid(bp.total);
-    static const bool stamp = [] { const char *e = getenv("PCCM_BRICK_STAMP"); return e && e[0] == '1'; }();
     bp.stamps = nullptr;
+#ifdef PCCM_DIAG   // diagnostic builds only (make DIAG=1): in-kernel stamps and the timing-only ablations never ship
+    static const bool stamp = [] { const char *e = getenv("PCCM_BRICK_STAMP"); return e && e[0] == '1'; }();
     if (stamp && !self && !ctx->capturing) {
         // diagnostic build: phase shares of the wave cycles, printed per launch (never part of a timed or captured run)
         static unsigned long long *dev = nullptr;
@@ -554,6 +558,7 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
         else hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 15>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         return;
     }
+#endif
     static const bool v_free = [] { const char *e = getenv("PCCM_BRICK_V64"); return e && e[0] == '0'; }();
     if (v_free && !self) {     // A/B: no register cap
         hipLaunchKernelGGL((k_brick_query_free<BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
@@ -573,7 +578,6 @@ int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, 
     if (bp.bx > kBXMax) bp.bx = kBXMax;
     bp.nbx = (g.dim[0] + bp.bx - 1) / bp.bx;
     bp.nby = bp.nbz = 0;
-    bp.m_nbx = bp.m_nby = 0u;
     bp.per_job = 0;
     bp.total = 0;
     bp.cap = 0;

@@ -19,6 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"PCCM_GRID_COOP": "0"},
     {"PCCM_GRID_REC64": "1"},
     {"PCCM_NO_FUSE": "1", "PCCM_BUILD_TILE": "2048"},
+    {"PCCM_BRICK_ABLATE": "7", "PCCM_BRICK_STAMP": "1"},      # diagnostics (make DIAG=1 only): the shipped library ignores them
+    {"PCCM_BRICK": "4,4", "PCCM_BRICK_CAP": "3800"},          # 4 x 4 bricks at the LDS clamp
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_ab_path_gives_the_same_report(env):
     child = dict(os.environ)

@@ -44,6 +44,21 @@ def test_bench_two_gloo_ranks_print_one_valid_line():
     assert abs(solo["value"] - 2 * 2 * 300000 / (solo["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * solo["value"]
 
 
+def test_bench_launches_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts the ranks itself as a child process
+    (before any GPU call) and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--points", "200000",
+           "--backend", "gloo", "--no-extras"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS="2"))
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["steps"] == 4
+    assert line["config"]["sharding"] == "direction x2" and line["value"] > 0
+
+
 NCCL_WORKER = r'''
 import os, sys
 import numpy as np

@@ -65,3 +65,11 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "pccm.h"\nint main(void) { return pccm_version() > 0 ? 0 : 1; }\n')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
+
+
+def test_shipped_library_carries_no_diagnostic_instantiations():
+    """the timing-only ablations (wrong results by construction) and the stamp-printing kernel compile only
+    with `make DIAG=1`; the shipped libpccm.so does not even read their switches."""
+    blob = open(os.path.join(ROOT, "open_pcc_metric_amd", "csrc", "libpccm.so"), "rb").read()
+    for name in (b"PCCM_BRICK_ABLATE", b"PCCM_BRICK_STAMP"):
+        assert name not in blob, f"{name.decode()} is compiled into the product library"

@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _torchrun(script, nproc, env, timeout):
-    """Launch `nproc` gloo ranks of `script`; one retry on a fresh port if the rendezvous fails (the probed port can be taken
-    between the probe and torchrun's bind on a busy host)."""
+    """Launch `nproc` gloo ranks of `script`; one retry on a fresh port, and ONLY if stderr shows a bind / rendezvous failure (the
+    probed port can be taken between the probe and torchrun's bind on a busy host); any other failure is returned as it is."""
     import socket
     proc = None
     for _ in range(2):
@@ -27,6 +27,9 @@ def _torchrun(script, nproc, env, timeout):
         proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
         if proc.returncode == 0:
             break
+        err = proc.stderr.lower()
+        if not any(t in err for t in ("eaddrinuse", "address already in use", "rendezvouserror", "rendezvous")):
+            break                      # a worker failed: surface it, never retry an assertion away
     return proc
 
 WORKER = r'''
