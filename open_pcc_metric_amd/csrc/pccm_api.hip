@@ -115,6 +115,10 @@ static void free_cloud(Cloud &c)
     if (c.nrm64) (void)hipFree(c.nrm64);
     if (c.nrm32) (void)hipFree(c.nrm32);
     if (c.rgb64) (void)hipFree(c.rgb64);
+    if (c.sp) (void)hipFree(c.sp);
+    c.sp = nullptr;
+    c.cap_sp = 0;
+    c.sp_valid = false;
     c.xyz32 = nullptr;
     c.xyz64 = nullptr;
     c.nrm64 = nullptr;
@@ -125,7 +129,11 @@ static void free_cloud(Cloud &c)
 }
 
 // forget the content, keep the allocations
-static void drop_cloud(Cloud &c) { c.n = c.n_pad = c.n_nrm = c.n_rgb = 0; }
+static void drop_cloud(Cloud &c)
+{
+    c.n = c.n_pad = c.n_nrm = c.n_rgb = 0;
+    c.sp_valid = false;
+}
 
 static void free_nn(NNResult &r)
 {
@@ -343,7 +351,7 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
         c.bb_min[k] = unkey(h[3 + k]);
         c.bb_max[k] = unkey(h[6 + k]);
     }
-    return PCCM_OK;
+    return spatial_order(ctx, c);
 }
 
 int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype, int on_device)
@@ -1047,11 +1055,19 @@ static ReduceSlot *slot_find(pccm_ctx *ctx, int dir, int metric, int normal_mode
     return nullptr;
 }
 
-static ReduceSlot *slot_free(pccm_ctx *ctx)
+// A slot for a new reduction: an idle or stale one; failing that, a pending one that does NOT belong to the batch being
+// assembled (`fresh`): its unconsumed result is given up (a later pccm_reduce recomputes it) -- never a slot of the current
+// batch, whose host buffers an earlier job of the same launch is about to write.
+static ReduceSlot *slot_free(pccm_ctx *ctx, ReduceSlot *const *fresh, int nfresh)
 {
     for (auto &s : ctx->slots)
         if (!s.pending || s.gen != ctx->nn_gen[s.dir]) return &s;
-    return &ctx->slots[0];
+    for (auto &s : ctx->slots) {
+        bool mine = false;
+        for (int k = 0; k < nfresh; ++k) mine = mine || fresh[k] == &s;
+        if (!mine) return &s;
+    }
+    return nullptr;
 }
 
 static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metrics, const int *normal_modes, bool want_units);
@@ -1097,7 +1113,8 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
     for (int k = 0; k < n; ++k) {
         if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
         if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k], want_units)) continue;
-        ReduceSlot *s = slot_free(ctx);
+        ReduceSlot *s = slot_free(ctx, fresh, nfresh);
+        if (!s) return fail(PCCM_E_STATE, "no free reduction slot: more than 8 live columns in one batch");
         if (s->pending && !ctx->capturing && s->wait_ev) PCCM_HIP(hipEventSynchronize(s->wait_ev));
         s->pending = false;
         int rc = slot_prepare(ctx, *s, dirs[k], metrics[k], normal_modes[k], want_units, pj, uj);

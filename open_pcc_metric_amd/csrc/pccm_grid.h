@@ -9,8 +9,20 @@ namespace pccm {
 
 struct GridGeom {
     int dim[3];
+    int morton = 0;      // cells are numbered along a Z-order curve (dims are equal powers of two): the ingest-time spatial sort
     double org[3], h[3], inv_h[3], slack[3];
 };
+
+// x | y << 1 | z << 2 per bit: 10 bits per axis
+__device__ __forceinline__ uint32_t spread3(uint32_t v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
 
 __device__ __forceinline__ int cell_coord(double v, double org, double inv_h, int dim)
 {
@@ -26,6 +38,7 @@ __device__ __forceinline__ uint32_t cell_linear(const GridGeom &g, double x, dou
     const int cx = cell_coord(x, g.org[0], g.inv_h[0], g.dim[0]);
     const int cy = cell_coord(y, g.org[1], g.inv_h[1], g.dim[1]);
     const int cz = cell_coord(z, g.org[2], g.inv_h[2], g.dim[2]);
+    if (g.morton) return spread3((uint32_t)cx) | (spread3((uint32_t)cy) << 1) | (spread3((uint32_t)cz) << 2);
     return ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
 }
 
@@ -93,6 +106,8 @@ struct BuildJob {
     const float *x32;    // quad layout (Cloud::xyz32); read instead of x64 when the records are Rec32
     int64_t row0, n;     // rows [row0, row0 + n)
     uint32_t *cs;        // this job's cell starts, [ncells + 1]
+    const Rec32 *sp = nullptr;   // the cloud in its ingest-time spatial order ({x, y, z, original row}; Cloud::sp), read instead
+                                 // of x32 when the job covers the whole cloud: the sort's scatters then stay inside a few bins
 };
 
 struct BuildJobs {

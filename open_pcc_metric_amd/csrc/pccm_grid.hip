@@ -813,6 +813,43 @@ int grid_decide(pccm_ctx *ctx, bool *hostile)
     return PCCM_OK;
 }
 
+// ---- ingest-time spatial order (Cloud::sp) --------------------------------------------------------------------
+// One counting sort of the cloud along a Z-order curve over its own bounding box (2^b cells per axis, ~4 points per cell):
+// the same three kernels as the grid build, with Morton-numbered cells.  Per cloud, once per pccm_set_cloud -- part of
+// `end_to_end` / `cold_pair`, not of a step (whose build re-sorts this array into the pair's grid every time).
+// PCCM_SPATIAL=0 switches it off (A/B runs: the build then reads the rows in the caller's order, as in round 2).
+int spatial_order(pccm_ctx *ctx, Cloud &c)
+{
+    c.sp_valid = false;
+    static const bool off = [] { const char *e = getenv("PCCM_SPATIAL"); return e && e[0] == '0'; }();
+    if (off || !c.exact32 || c.n < 4096) return PCCM_OK;            // small clouds: nothing to gain
+    int bits = 4;
+    while (bits < 8 && (double)(1ll << (3 * (bits + 1))) * 4.0 <= (double)c.n * 2.0) ++bits;   // ~4 points per cell
+    GridGeom g;
+    g.morton = 1;
+    for (int a = 0; a < 3; ++a) {
+        const double ext = c.bb_max[a] - c.bb_min[a];
+        g.dim[a] = 1 << bits;
+        g.org[a] = c.bb_min[a];
+        g.h[a] = ext > 0.0 ? ext / g.dim[a] * (1.0 + 0x1.0p-40) : 1.0;
+        g.inv_h[a] = 1.0 / g.h[a];
+        g.slack[a] = 0.0;
+    }
+    const int64_t ncells = 1ll << (3 * bits);
+    int rc;
+    if ((rc = grow(&c.sp, c.cap_sp, (size_t)c.n * sizeof(Rec32)))) return rc;
+    if ((rc = ensure(ctx, ctx->g_hist, (size_t)3 * (ncells + 1) * sizeof(uint32_t)))) return rc;
+    ProfScope ps(ctx, PCCM_K_INGEST);
+    BuildJobs jobs;
+    jobs.njobs = 1;
+    jobs.total = c.n;
+    jobs.j[0] = {c.xyz64, (const float *)c.xyz32, 0, c.n, (uint32_t *)ctx->g_hist.p};
+    jobs.j[1] = jobs.j[0];
+    if ((rc = sort_by_cell(ctx, jobs, g, ncells, c.sp, true))) return rc;
+    c.sp_valid = true;
+    return PCCM_OK;
+}
+
 // record layout for the current pair: Rec32 when both clouds are fp32-exact (PCCM_GRID_REC64=1 forces GridRec, for A/B runs)
 static bool pair_rec32(const pccm_ctx *ctx)
 {
@@ -863,7 +900,9 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
         if (!(need_mask & (1 << k))) continue;
         const Cloud &c = ctx->cloud[k];
         if (jobs.njobs == 0) first = (char *)gr.recs.p + (size_t)(k ? n0 : 0) * rsz;
-        jobs.j[jobs.njobs++] = {c.xyz64, (const float *)c.xyz32, 0, c.n, cs + (size_t)k * (ncells + 1)};
+        jobs.j[jobs.njobs] = {c.xyz64, (const float *)c.xyz32, 0, c.n, cs + (size_t)k * (ncells + 1)};
+        if (rec32 && c.sp_valid) jobs.j[jobs.njobs].sp = (const Rec32 *)c.sp;
+        ++jobs.njobs;
         jobs.total += c.n;
     }
     if (jobs.njobs == 1) jobs.j[1] = jobs.j[0];

@@ -137,6 +137,7 @@ struct BinJob {
     int64_t hoff;          // first hist entry of this job (= nbin * tiles of the jobs before it)
     int64_t base;          // records of the jobs before this one
     int64_t tile0;         // tiles of the jobs before this one
+    const float4 *sp;      // the cloud in its spatial order, {x, y, z, original row} (BuildJob::sp), or null
 };
 
 struct BinPlan {
@@ -209,7 +210,20 @@ __global__ __launch_bounds__(1024) void k_bin_count(BinPlan P, GridGeom g, uint3
     const int jb = tile_job(P, tile);
     const BinJob &J = P.j[jb];
     const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
-    if (X32) {
+    if (X32 && J.sp) {
+        // the cloud in its spatial order: one 16-byte record per row, eight independent rows per trip
+        for (int64_t i = i0 + tid; i < i1; i += 8 * nth) {
+            float4 r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t ii = i + (int64_t)nth * k;
+                r[k] = J.sp[J.row0 + (ii < i1 ? ii : i1 - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i + (int64_t)nth * k < i1) atomicAdd(&s_hist[cell_linear(g, (double)r[k].x, (double)r[k].y, (double)r[k].z) >> P.lg], 1u);
+        }
+    } else if (X32) {
         // a thread takes whole quads of rows (three 16-byte loads each, every byte of a line used), two quads per trip
         const int64_t nquad = (i1 - i0 + 3) >> 2;
         for (int64_t qd = tid; qd < nquad; qd += 2 * nth) {
@@ -302,6 +316,25 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(BinPlan P, GridGeom g, con
     }
     __syncthreads();
     const int64_t i0 = tile * J.tl, i1 = (i0 + J.tl < J.n) ? i0 + J.tl : J.n;
+    if (X32 && J.sp) {
+        // spatial order: the record is already there (with its original row); it only has to find its bin
+        float4 *__restrict__ out = reinterpret_cast<float4 *>(tmp);
+        for (int64_t i = i0 + tid; i < i1; i += 8 * nth) {
+            float4 r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t ii = i + (int64_t)nth * k;
+                r[k] = J.sp[J.row0 + (ii < i1 ? ii : i1 - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i + (int64_t)nth * k < i1) {
+                    const uint32_t pos = atomicAdd(&s_cur[cell_linear(g, (double)r[k].x, (double)r[k].y, (double)r[k].z) >> P.lg], 1u);
+                    if (sizeof(REC) == 16) out[pos] = r[k];
+                }
+        }
+        return;
+    }
     if (X32) {
         const int64_t nquad = (i1 - i0 + 3) >> 2;
         for (int64_t qd = tid; qd < nquad; qd += 2 * nth) {
@@ -488,6 +521,7 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
         const BuildJob &s = jobs.j[k < jobs.njobs ? k : 0];
         BinJob &d = P.j[k];
         d.x64 = s.x64; d.x32 = s.x32; d.row0 = s.row0; d.cs = s.cs;
+        d.sp = rec32 ? reinterpret_cast<const float4 *>(s.sp) : nullptr;
         if (rec32 && k < jobs.njobs && (s.row0 & 3)) return fail(PCCM_E_ARG, "a shard must start on a multiple of 4 rows (it starts on 128-row units)");
         d.n = k < jobs.njobs ? s.n : 0;
         // rows per tile: with bin cursors every (tile, bin) costs one returning atomic and one toff word, so larger tiles

@@ -36,6 +36,13 @@ struct Cloud {
     int64_t n_rgb = 0;
     // allocations outlive their content (n / n_nrm / n_rgb say what is there): a context that serves one pair after
     // the other -- the engine pool of _native.py -- does not pay hipFree + hipMalloc per cloud
+    // the same points in a spatially coherent order (fp32-exact clouds): Rec32 {x, y, z, original row} sorted along a Z-order
+    // curve over the cloud's own bounding box, made once at ingest (pccm_set_cloud).  The per-step grid build reads it instead
+    // of xyz32: rows that are neighbours in memory are neighbours in space, so the counting sort's scattered stores fall into a
+    // few bins per tile and merge into whole lines (WRITE_SIZE 2x -> ~1x the records).  Results never depend on it.
+    void *sp = nullptr;
+    size_t cap_sp = 0;
+    bool sp_valid = false;
     size_t cap32 = 0, cap64 = 0, cap_nrm = 0, cap_nrm32 = 0, cap_rgb = 0;
     bool exact32 = true;        // every coordinate survives the fp64 -> fp32 -> fp64 round trip
     bool all_int = false;       // ... and is an integer (voxelised content: exact ties are the rule)
@@ -230,6 +237,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx = 0);   // 
 void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
 int grid_ensure(pccm_ctx *ctx, bool need64 = false, int need_mask = 3);   // need64: GridRec records wanted (pccm_normals.hip reads them)
+int spatial_order(pccm_ctx *ctx, Cloud &c);      // fills Cloud::sp (ingest; no-op for clouds that are not fp32-exact)
 int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the current pair (cached per pair)
 int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)
 int estimate_normals(pccm_ctx *ctx, int which, int k);
