@@ -82,7 +82,8 @@ __device__ __forceinline__ void load_normal(const NNOut &o, int row, double &a, 
     }
 }
 
-template <bool SELF, int BY, int BZ, bool STAMP, int ABL>   // ABL: timing-only ablations (PCCM_BRICK_ABLATE), wrong results
+// N32: every job's normals (if any are fused) are the fp32-exact 16-byte words of nrm32
+template <bool SELF, int BY, int BZ, bool STAMP, int ABL, bool N32>   // ABL: timing-only ablations (PCCM_BRICK_ABLATE), wrong results
 __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom &g, const BrickParams &bp, const uint32_t vblock)
 {
     if (ABL & 32) return;                                              // timing only: the empty launch
@@ -195,15 +196,14 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         return;
     }
 
-    // the lane's first query is fetched while the brick is staged
+    // the lane's first query is fetched while the brick is staged: its load is issued BEHIND the staging loads (step 2b) --
+    // issued first, hipcc copies its row word right behind the load and parks the wave on a full memory round trip before a
+    // single staging load has left (round 2's kernel did: ISA, `global_load_dwordx4 ; s_waitcnt vmcnt(0) ; v_mov`)
     uint32_t qi = tid;
     bool have = qi < NQ;
     int rn = 0;
     float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (have) {
-        rn = query_row(qi);
-        qn = load_query(qi, rn);
-    }
+    if (have) rn = query_row(qi);
 
     // ---- 2. stage cell starts (wave w: runs w, w + NT/64, ...) and records (interleaved 64-record pieces) -------
     // Every global load of a batch is issued before the first LDS write that depends on one (a copy loop that loads,
@@ -212,7 +212,21 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
     const NNOut &out = J.out;
     const bool fuse = out.nrm != nullptr;
     const bool fuse_row = fuse && out.normal_mode == PCCM_NORMAL_ROW;
-    double n0 = 0.0, n1 = 0.0, n2 = 0.0;                               // row-indexed normal of the lane's current query
+    // row-indexed normal of the lane's current query, AS LOADED (the 16-byte word of nrm32, or the fp64 row): a conversion at
+    // the load makes the wave wait for the gather -- a random access -- in front of the barrier (round 2's kernel did);
+    // converted in the epilogue instead.  The load is unconditional (a lane without a query, or a job without normals, reads
+    // the first query record of the job instead): a conditional one ends in register copies behind the load, i.e. the same wait.
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    float4 nraw = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gather_row_normal = [&](int row, bool on) {
+        if (N32) {
+            const float4 *src = on ? out.nrm32 + row : reinterpret_cast<const float4 *>(qbase);
+            nraw = *src;
+        } else if (on) {
+            const double *np = out.nrm + 3 * (int64_t)row;
+            n0 = np[0]; n1 = np[1]; n2 = np[2];
+        }
+    };
     {
         const int nw = NT >> 6;
         // Wave w copies runs w, w + nw, w + 2 nw (a run = the records of BX + 2 consecutive cells, contiguous in the
@@ -262,6 +276,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
                     }
                 }
             }
+            if (have && r0 == w) qn = load_query(qi, rn);             // (the youngest load: nothing below waits for it)
             // c. the LDS writes (in the order the loads return)
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -311,9 +326,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         // d. the first query has arrived with the records (loads return in order): its row-indexed normal (quirk Q1)
         //    travels while the workgroup meets at the barrier and scans
         __builtin_amdgcn_sched_barrier(0);
-        if (have && fuse_row) {
-            load_normal(out, __float_as_int(qn.w), n0, n1, n2);
-        }
+        gather_row_normal(__float_as_int(qn.w), have && fuse_row);
     }
     BRICK_STAMP(1);                                                    // staging issued (+ waits of its loads)
     __syncthreads();
@@ -325,7 +338,6 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         const float4 q = qn;
         const int r = rn;
         const int qrow = __float_as_int(q.w);
-        const double m0 = n0, m1 = n1, m2 = n2;
         const uint32_t qnext = qi + NT;
         const bool hn = qnext < NQ;                                    // a leftover query (rare: the workgroup is sized to the brick)
         const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
@@ -413,7 +425,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
             if (settled) {
                 double p = 0.0;
                 if (fuse) {
-                    double e0 = m0, e1 = m1, e2 = m2;
+                    double e0 = N32 ? (double)nraw.x : n0, e1 = N32 ? (double)nraw.y : n1, e2 = N32 ? (double)nraw.z : n2;
                     if (!fuse_row) {
                         load_normal(out, wrow, e0, e1, e2);
                     }
@@ -432,9 +444,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         if (hn) {                                                      // fetched only now: keeps the scan's registers free
             rn = query_row(qnext);
             qn = load_query(qnext, rn);
-            if (fuse_row) {
-                load_normal(out, __float_as_int(qn.w), n0, n1, n2);
-            }
+            gather_row_normal(__float_as_int(qn.w), fuse_row);
         }
         qi = qnext;
         have = hn;
@@ -457,16 +467,16 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
 // kernel lives on occupancy (two workgroups per CU: 148 us, three: 112 us, four: 104 us at 1M points).  With 81-96 SGPRs
 // the hardware admits one wave per SIMD less than the compiler's occupancy figure says (MI355X_MICROARCH.md, "Residency
 // and cooperative launch").  PCCM_BRICK_V64=0 runs the build without the cap (72 VGPRs, 93 SGPRs) for A/B.
-template <bool SELF, int BY, int BZ, bool STAMP = false, int ABL = 0>
+template <bool SELF, int BY, int BZ, bool STAMP = false, int ABL = 0, bool N32 = true>
 __global__ __launch_bounds__(1024, 8) void k_brick_query(QueryJobs jobs, GridGeom g, BrickParams bp)
 {
-    brick_body<SELF, BY, BZ, STAMP, ABL>(jobs, g, bp, blockIdx.x);
+    brick_body<SELF, BY, BZ, STAMP, ABL, N32>(jobs, g, bp, blockIdx.x);
 }
 
 template <int BY, int BZ>
 __global__ __launch_bounds__(1024) void k_brick_query_free(QueryJobs jobs, GridGeom g, BrickParams bp)
 {
-    brick_body<false, BY, BZ, false, 0>(jobs, g, bp, blockIdx.x);
+    brick_body<false, BY, BZ, false, 0, false>(jobs, g, bp, blockIdx.x);
 }
 
 // brick shape: PCCM_BRICK="BY,BZ[,NT]" picks one of the compiled shapes and optionally forces the workgroup size (A/B runs)
@@ -564,8 +574,12 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
         hipLaunchKernelGGL((k_brick_query_free<BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         return;
     }
-    if (self) hipLaunchKernelGGL((k_brick_query<true, BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-    else hipLaunchKernelGGL((k_brick_query<false, BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+    // fp32-exact normals (file normals) or none fused: the kernel that carries the 16-byte word; fp64 rows (estimated normals) else
+    bool n32 = true;
+    for (int k = 0; k < jobs.njobs; ++k) n32 = n32 && (jobs.j[k].out.nrm == nullptr || jobs.j[k].out.nrm32 != nullptr);
+    if (self) hipLaunchKernelGGL((k_brick_query<true, BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);     // (no normals in a self search)
+    else if (n32) hipLaunchKernelGGL((k_brick_query<false, BY, BZ, false, 0, true>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+    else hipLaunchKernelGGL((k_brick_query<false, BY, BZ, false, 0, false>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
 }
 
 int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self)
