@@ -52,6 +52,23 @@ def synth(n):
     return a, b, unit(4321), unit(8765)
 
 
+def synth_content(target=800_000, seed=11):
+    """A configs[4]-class pair (BASELINE.json: 8i longdress vs decoded rates; the real files are not here): a 10-bit voxelised
+    closed surface of `target` points (integer coordinates, exact distance ties are the rule) and a "decoded" version of it --
+    voxel jitter, duplicates merged, a tenth of the points dropped.  No normals (PLY content has none)."""
+    rng = np.random.default_rng(seed)
+    m = 6 * target
+    u = rng.random(m) * 2 * np.pi
+    v = np.arccos(2 * rng.random(m) - 1)
+    r = 250 + 22 * np.sin(3 * u) * np.sin(5 * v) + 6 * np.sin(17 * u + 3 * v)
+    p = np.stack([512 + r * np.sin(v) * np.cos(u), 512 + 0.62 * r * np.sin(v) * np.sin(u), 512 + r * np.cos(v)], 1)
+    a = np.unique(np.round(p).astype(np.float32), axis=0)
+    a = a[rng.permutation(len(a))[:target]]
+    b = np.unique((a + np.rint(rng.normal(0, 0.45, a.shape))).astype(np.float32), axis=0)
+    b = b[rng.random(len(b)) >= 0.1]
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
 def cpu_baseline(a, b, na, nb):
     """The oracle (CPU restatement: exact kd-tree 1-NN in C/OpenMP + NumPy reductions) timed on this
     host for the SAME workload as one GPU step.  Reported baseline, not a target."""
@@ -131,6 +148,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="default: 5 (1 with --engine brute)")
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--engine", default="auto", choices=["auto", "brute", "grid"])
+    ap.add_argument("--content-only", action="store_true",
+                    help="profiling runs: time only the `content` record's step (voxelised-surface pair, D1 + Hausdorff) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip full_report / cold_pair / brute / end_to_end (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying a hipGraph")
@@ -183,6 +202,44 @@ def main():
         else:
             dist.init_process_group("gloo")
         group = dist.group.WORLD
+
+    def content_record(steps):
+        """One step on PCC-like content: both clouds resident, grid build + both sweeps + D1 MSE / PSNR / Hausdorff rows."""
+        ca, cb = synth_content()
+        copts = CalculateOptions(color=None, hausdorff=True, point_to_plane=False)
+        with CloudPair(PointCloud(ca), PointCloud(cb), extent=[511.0, 322.0, 505.0], device=local, nn_engine=args.engine,
+                       use_graph=not args.no_graph) as cp:
+            ce = cp._engine
+
+            def cstep():
+                cp.recompute()
+                return MetricCalculator(cp).calculate(transform_options(copts)[2:]).as_dict()
+
+            for _ in range(4):
+                cstep()
+            ce.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                cres = cstep()
+            ce.sync()
+            dt = (time.perf_counter() - t0) / steps
+            cp._use_graph = False
+            ce.profile(True)
+            ce.profile_reset()
+            for _ in range(5):
+                cstep()
+            ce.sync()
+            kus = {k: round(ce.profile_get(k)[0] / 5 * 1e3, 1) for k in nat.KERNEL_CLASSES if ce.profile_get(k)[1]}
+            ce.profile(False)
+            return {"ms_per_step": round(dt * 1e3, 4), "value": round((len(ca) + len(cb)) / dt / 1e6, 2), "unit": "Mpoints/s",
+                    "points": [len(ca), len(cb)], "kernel_us_per_step": kus, "grid_cells": ce.nn_stats(0)["splits"],
+                    "mse_left": float(cres[("GeoMSE", True, False)]),
+                    "note": "10-bit voxelised closed surface vs a jittered / thinned copy (BASELINE configs[4]-class content; the real "
+                            "longdress files are not in the container), D1 MSE / PSNR / Hausdorff, both directions + symmetric"}
+
+    if args.content_only:
+        print(json.dumps({"content": content_record(args.steps or 50)}), flush=True)
+        return
 
     n = args.points
     a, b, na, nb = synth(n)
@@ -341,6 +398,9 @@ def main():
                                                    "reduction: every row transform_options() returns, plus the D1 Hausdorff rows"}
         for _ in range(nwarm):                         # back to the headline report (re-captures its graph)
             result = step()
+
+        # (1b) PCC-like content: voxelised surfaces take the per-thread search, not the brick kernel
+        line["content"] = content_record(30)
 
         # (2) end to end, for the record (never `value`): a FRESH pair per iteration -- upload of both clouds and their
         # normals from pageable host memory, ingest, both sweeps, the same report -- through the pooled context

@@ -106,6 +106,8 @@ struct BuildJob {
     const float *x32;    // quad layout (Cloud::xyz32); read instead of x64 when the records are Rec32
     int64_t row0, n;     // rows [row0, row0 + n)
     uint32_t *cs;        // this job's cell starts, [ncells + 1]
+    uint32_t *occ = nullptr;     // occupancy bitmap to write next to cs: one bit per cell, set when the cell holds a record
+                                 // ([ncells / 32 + 2] words; voxelised pairs, pccm_lattice.hip), or null
     const Rec32 *sp = nullptr;   // the cloud in its ingest-time spatial order ({x, y, z, original row}; Cloud::sp), read instead
                                  // of x32 when the job covers the whole cloud: the sort's scatters then stay inside a few bins
 };
@@ -182,6 +184,7 @@ struct QueryJob {
     const uint32_t *qcs;        // query cloud's (or shard's) cell starts
     int64_t nq, nchunks;        // nchunks = ceil(nq / 64)
     const uint32_t *cs;         // searched cloud's cell starts (positions in srecs)
+    const uint32_t *occ;        // ... and its occupancy bitmap (voxelised pairs), or null
     const void *srecs;          // searched cloud's records
     const double *s64;          // searched cloud's fp64 rows (emit_result_lookup)
     int64_t row_base;           // first row of the shard (outputs are indexed row - row_base)
@@ -218,6 +221,9 @@ __device__ __forceinline__ bool settled_by(double L, double d)
 {
     return (L == INFINITY) || (L > 0.0 && d < L * L * (1.0 - 0x1.0p-30));
 }
+
+// per-thread search for voxelised (integer-valued) pairs on Rec32 grids (pccm_lattice.hip)
+int launch_lattice_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self);
 
 // LDS-brick ring-1 kernel for Rec32 grids (pccm_brick.hip)
 int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self);

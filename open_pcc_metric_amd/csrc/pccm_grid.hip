@@ -857,6 +857,17 @@ static bool pair_rec32(const pccm_ctx *ctx)
     return !force64 && ctx->cloud[0].exact32 && ctx->cloud[1].exact32;
 }
 
+// Voxelised pairs on the per-thread path: fp32 arithmetic is exact for every candidate the rings can reach (integers below
+// 2^22, cells of at most 256 units: differences below 2^11, squared distances below 2^24) -- pccm_lattice.hip, which asks the
+// searched cloud's occupancy bitmap before it touches cell starts.  PCCM_LATTICE=0: the general per-thread kernel.
+static bool lattice_pair(const pccm_ctx *ctx, const GridGeom &g, bool rec32)
+{
+    static const bool off = [] { const char *e = getenv("PCCM_LATTICE"); return e && e[0] == '0'; }();
+    const Cloud &c0 = ctx->cloud[0], &c1 = ctx->cloud[1];
+    return rec32 && !off && !use_coop(ctx) && c0.all_int && c1.all_int && c0.maxabs < 4194304.0 && c1.maxabs < 4194304.0 &&
+           g.h[0] <= 256.0 && g.h[1] <= 256.0 && g.h[2] <= 256.0;
+}
+
 // (re)build the combined grid when either cloud changed, the caches were dropped or the record layout asked for
 // differs from the built one (need64: a caller that reads GridRec records, pccm_normals.hip)
 // A shard's rows of the iterating cloud that want the same cell sort as the grid being built: when exactly one cloud is
@@ -876,7 +887,8 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
     Grid &gr = ctx->grid;
     const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
     const bool rec32 = !need64 && pair_rec32(ctx);
-    const bool same = gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p && gr.rec32 == rec32;
+    const bool same = gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p && gr.rec32 == rec32 &&
+                      (!rec32 || gr.lattice == lattice_pair(ctx, geom_of(gr), rec32));
     if (same && (gr.built & need_mask) == need_mask) return PCCM_OK;
     if (same) need_mask |= gr.built;                   // keep what is there, add what is missing
     int rc0 = decide_scale(ctx, key);
@@ -890,6 +902,9 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
     if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;   // either layout fits
     uint32_t *cs = (uint32_t *)gr.cell_start.p;
+    const bool lattice = lattice_pair(ctx, g, rec32);
+    const int64_t occ_words = ncells / 32 + 2;
+    if (lattice && (rc = ensure(ctx, gr.occ, (size_t)2 * occ_words * sizeof(uint32_t)))) return rc;
     const size_t rsz = rec32 ? sizeof(Rec32) : sizeof(GridRec);
     // cloud k's records live at recs + (k ? n0 : 0) whichever clouds are built; cell starts are relative to that
     BuildJobs jobs;
@@ -902,6 +917,7 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
         if (jobs.njobs == 0) first = (char *)gr.recs.p + (size_t)(k ? n0 : 0) * rsz;
         jobs.j[jobs.njobs] = {c.xyz64, (const float *)c.xyz32, 0, c.n, cs + (size_t)k * (ncells + 1)};
         if (rec32 && c.sp_valid) jobs.j[jobs.njobs].sp = (const Rec32 *)c.sp;
+        if (lattice) jobs.j[jobs.njobs].occ = (uint32_t *)gr.occ.p + (size_t)k * occ_words;
         ++jobs.njobs;
         jobs.total += c.n;
     }
@@ -930,6 +946,7 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
     gr.n[1] = n1;
     gr.key = key;
     gr.rec32 = rec32;
+    gr.lattice = lattice;
     gr.built = need_mask;
     return PCCM_OK;
 }
@@ -1143,6 +1160,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         J.nq = nq;
         J.nchunks = (nq + 63) / 64;
         J.cs = cs_all + (si ? gr.ncells + 1 : 0);
+        J.occ = gr.lattice ? (const uint32_t *)gr.occ.p + (size_t)si * (gr.ncells / 32 + 2) : nullptr;
         J.srecs = recs_all + (size_t)(si ? gr.n[0] : 0) * rsz;
         J.s64 = se.xyz64;
         J.row_base = res.begin;
@@ -1240,7 +1258,9 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         } else {
             dim3 grid((unsigned)qblocks);
             ProfScope ps(ctx, PCCM_K_GRID_QUERY);
-            if (gr.rec32) launch_queries<Rec32>(ctx, jobs, g, self, true, grid);
+            if (gr.lattice) {                                // voxelised pair: pccm_lattice.hip
+                if ((rc = launch_lattice_query(ctx, jobs, g, self))) return rc;
+            } else if (gr.rec32) launch_queries<Rec32>(ctx, jobs, g, self, true, grid);
             else launch_queries<GridRec>(ctx, jobs, g, self, true, grid);
         }
         PCCM_HIP(hipGetLastError());
@@ -1263,7 +1283,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
 
 void grid_release(pccm_ctx *ctx)
 {
-    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.recs, &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum,
+    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.occ, &ctx->grid.recs, &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum,
                       &ctx->g_qrecs, &ctx->g_bins, &ctx->g_tmp};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);

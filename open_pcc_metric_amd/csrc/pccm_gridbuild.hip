@@ -138,7 +138,30 @@ struct BinJob {
     int64_t base;          // records of the jobs before this one
     int64_t tile0;         // tiles of the jobs before this one
     const float4 *sp;      // the cloud in its spatial order, {x, y, z, original row} (BuildJob::sp), or null
+    uint32_t *occ;         // occupancy bitmap to write (BuildJob::occ), or null
 };
+
+// cell starts of a bin out of its scanned counters (s_cnt[c] = records of the bin before cell c; m = records of the bin;
+// first = the bin's first record, relative to the job's), and -- when the job keeps one -- the occupancy bitmap: one bit per
+// cell, set when the cell holds a record (every wave covers 64 consecutive cells, i.e. two whole words: bins start on
+// multiples of 1024 cells)
+__device__ __forceinline__ void write_cell_starts(const BinJob &J, const uint32_t *s_cnt, int64_t c0, int nc, uint32_t first, uint32_t m)
+{
+    const int tid = threadIdx.x, nth = (int)blockDim.x;
+    if (!J.occ) {
+        for (int c = tid; c < nc; c += nth) J.cs[c0 + c] = first + s_cnt[c];
+        return;
+    }
+    for (int c = tid; c < ((nc + 63) & ~63); c += nth) {
+        const uint32_t here = c < nc ? s_cnt[c] : m, next = c + 1 < nc ? s_cnt[c + 1] : m;
+        if (c < nc) J.cs[c0 + c] = first + here;
+        const unsigned long long bits = __ballot(next != here);
+        if ((tid & 63) == 0) {
+            J.occ[(c0 + c) >> 5] = (uint32_t)bits;
+            J.occ[((c0 + c) >> 5) + 1] = (uint32_t)(bits >> 32);
+        }
+    }
+}
 
 struct BinPlan {
     BinJob j[2];
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(256, sizeof(REC) == 16 ? 6 : 4) void k_bin_sort(Bin
             }
         __syncthreads();
         block_scan_inplace(s_cnt, nc, s_wsum, &s_carry);
-        for (int c = tid; c < nc; c += 256) J.cs[c0 + c] = s - j0 + s_cnt[c];
+        write_cell_starts(J, s_cnt, c0, nc, s - j0, m);
 #pragma unroll
         for (int k = 0; k < kRegK; ++k)
             if (tid + 256u * k < m) dst[s + s_cnt[cell[k]] + rank[k]] = v[k];
@@ -482,7 +505,7 @@ __global__ __launch_bounds__(256, sizeof(REC) == 16 ? 6 : 4) void k_bin_sort(Bin
         }
         __syncthreads();
         block_scan_inplace(s_cnt, nc, s_wsum, &s_carry);
-        for (int c = tid; c < nc; c += 256) J.cs[c0 + c] = s - j0 + s_cnt[c];
+        write_cell_starts(J, s_cnt, c0, nc, s - j0, m);
         __syncthreads();                                   // cell_start is out: the offsets become cursors
         for (uint32_t i = tid; i < m; i += 256) {
             const P3 v = load_rec(tmp, s + i);
@@ -522,6 +545,7 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
         BinJob &d = P.j[k];
         d.x64 = s.x64; d.x32 = s.x32; d.row0 = s.row0; d.cs = s.cs;
         d.sp = rec32 ? reinterpret_cast<const float4 *>(s.sp) : nullptr;
+        d.occ = s.occ;
         if (rec32 && k < jobs.njobs && (s.row0 & 3)) return fail(PCCM_E_ARG, "a shard must start on a multiple of 4 rows (it starts on 128-row units)");
         d.n = k < jobs.njobs ? s.n : 0;
         // rows per tile: with bin cursors every (tile, bin) costs one returning atomic and one toff word, so larger tiles

@@ -120,6 +120,8 @@ struct Grid {                    // one geometry, both clouds (grid engine)
     double h[3] = {1, 1, 1}, inv_h[3] = {1, 1, 1};   // cell edge per axis
     int64_t ncells = 0, n[2] = {0, 0};
     DevBuf cell_start;             // uint32 [2][ncells + 1]: positions in recs
+    bool lattice = false;          // voxelised pair on the per-thread path: pccm_lattice.hip searches it, with the bitmap below
+    DevBuf occ;                    // uint32 [2][ncells / 32 + 2]: one bit per cell, set when the cell holds a record
     DevBuf recs;                   // GridRec or Rec32 [n[0] + n[1]]: cloud 0's records, then cloud 1's
 };
 
