@@ -159,6 +159,18 @@ int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2);
 /* get_left/right_error_vector(), cloud_pair.py:90-100: out[i][:] = iter[i] - search[nn(i)]. */
 int pccm_error_vectors(pccm_ctx *ctx, int dir, double *out);
 
+/* Diagnostic (opt-in, not on the report's path): how much of the point-to-plane result hangs on the ORDER OF EXACT TIES.
+ * get_neighbour_cloud() keeps idx[-1] of a one-neighbour nanoflann search (cloud_pair.py:22-23) -- whichever of several
+ * equidistant nearest points the tree meets; this library keeps the smallest row.  D1 is the same either way; the projection
+ * err . normal (metric.py:146-153) is not.  For the shard's rows of direction `dir` (0 or 1; the search must have run):
+ *   out[0] queries, out[1] queries with >= 2 equidistant nearest neighbours, out[2] / out[3] the sum over the queries of the
+ *   SMALLEST / LARGEST squared projection over all their nearest neighbours, out[4] the same sum for the library's own picks,
+ *   out[5] queries whose tie set was not enumerated (outliers far from the searched cloud: counted with their pick alone),
+ *   out[6] the largest tie multiplicity seen.
+ * out[2] / n_iter <= any admissible D2 MSE (the reference's included) <= out[3] / n_iter; tie-free data: out[1] = 0 and
+ * out[2] = out[3] = out[4].  normal_mode -1: counts only (no normals needed).  Sums are plain fp64 accumulations. */
+int pccm_tie_exposure(pccm_ctx *ctx, int dir, int normal_mode, double out[8]);
+
 /* Per-point metric vector of the shard (PCCM_METRIC_*), metric.py:124-179. */
 int pccm_point_metric(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *out);
 

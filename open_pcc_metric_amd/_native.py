@@ -30,7 +30,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
     "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_want_idx", "pccm_nn_fetch",
-    "pccm_error_vectors", "pccm_point_metric", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
+    "pccm_error_vectors", "pccm_point_metric", "pccm_tie_exposure", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total", "pccm_reduce_total_many", "pccm_cvec_len", "pccm_reduce_chunks_many", "pccm_finish_chunks",
     "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
     "pccm_color_transform", "pccm_lzf_decompress", "pccm_drop_caches", "pccm_graph_begin", "pccm_graph_end", "pccm_graph_launch", "pccm_graph_destroy",
@@ -98,6 +98,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_nn_fetch.argtypes = [vp, i32, vp, vp]
     lib.pccm_error_vectors.argtypes = [vp, i32, vp]
     lib.pccm_point_metric.argtypes = [vp, i32, i32, i32, vp]
+    lib.pccm_tie_exposure.argtypes = [vp, i32, i32, dp]
     lib.pccm_xvec_len.argtypes = [i64]
     lib.pccm_xvec_len.restype = i64
     lib.pccm_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
@@ -455,6 +456,15 @@ class Engine:
         _check(self._lib.pccm_point_metric(self._ctx, int(direction), int(metric), NORMAL_MODES[normal_mode],
                                            out.ctypes.data_as(ctypes.c_void_p)))
         return out
+
+    def tie_exposure(self, direction: int, normal_mode=None) -> dict:
+        """Diagnostic of include/pccm.h's pccm_tie_exposure for this shard's rows: how many queries have several
+        equidistant nearest neighbours, and the sums of the smallest / largest / chosen squared projection over them
+        (``normal_mode`` None: counts only)."""
+        out = (ctypes.c_double * 8)()
+        _check(self._lib.pccm_tie_exposure(self._ctx, int(direction), -1 if normal_mode is None else NORMAL_MODES[normal_mode], out))
+        return {"queries": int(out[0]), "tied": int(out[1]), "sum_min": float(out[2]), "sum_max": float(out[3]), "sum_pick": float(out[4]),
+                "not_enumerated": int(out[5]), "max_multiplicity": int(out[6])}
 
     def reduce_prefetch(self, direction: int, metric: int, normal_mode: str = "row") -> None:
         """Enqueue a reduction without waiting; a later reduce() with the same arguments consumes it."""

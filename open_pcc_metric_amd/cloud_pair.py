@@ -444,6 +444,34 @@ class CloudPair:
                 self._totals[key] = eng.reduce_total(direction, metric, self.normal_index)
         return self._totals[key]
 
+    def tie_exposure(self, is_left: bool = True, point_to_plane: bool = True) -> dict:
+        """Opt-in diagnostic (not part of any report): how far the order of EXACT ties can move the point-to-plane MSE.
+
+        The reference keeps whichever equidistant nearest neighbour nanoflann's traversal meets (cloud_pair.py:22-23),
+        this package the smallest row; D1 is identical either way, the projection (metric.py:146-153) is not.  Returns
+        for one direction: ``tie_rate`` (queries with >= 2 equidistant nearest neighbours), ``max_multiplicity``, and --
+        with ``point_to_plane`` -- ``d2_mse_min <= d2_mse_pick <= d2_mse_max``: the smallest / this package's / the largest
+        GeoMSE(point_to_plane=True) any tie rule can produce (the reference's value lies in that interval; on tie-free
+        data the three coincide).  Sums are plain fp64 accumulations: a diagnostic, not a bit-pinned metric."""
+        direction = nat.DIR_LEFT if is_left else nat.DIR_RIGHT
+        mode = None
+        if point_to_plane:
+            self._require_normals(1 if is_left else 0)
+            mode = self.normal_index
+        r = self._engine.tie_exposure(direction, mode)      # (the sweeps ran in the constructor / recompute)
+        vec = np.array([r["queries"], r["tied"], r["sum_min"], r["sum_max"], r["sum_pick"], r["not_enumerated"]], dtype=np.float64)
+        mult = np.array([float(r["max_multiplicity"])])
+        if self._coll.sharded:
+            vec = self._coll.allreduce(vec, "sum")
+            mult = self._coll.allreduce(mult, "max")
+        n = self._engine.n_iter(direction)
+        out = {"direction": "left" if is_left else "right", "queries": int(vec[0]), "tied_queries": int(vec[1]),
+               "tie_rate": float(vec[1] / max(vec[0], 1.0)), "max_multiplicity": int(mult[0]), "not_enumerated": int(vec[5])}
+        if point_to_plane:
+            out.update(d2_mse_min=float(vec[2] / n), d2_mse_max=float(vec[3] / n), d2_mse_pick=float(vec[4] / n),
+                       normal_index=self.normal_index)
+        return out
+
     def _neighbour_index(self, direction: int) -> np.ndarray:
         if direction not in self._idx_cache:
             idx, _ = self._engine.fetch_nn(direction, want_d2=False)

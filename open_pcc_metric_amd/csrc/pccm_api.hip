@@ -917,6 +917,21 @@ static int metric_on_device(pccm_ctx *ctx, int dir, int metric, int normal_mode,
     return PCCM_OK;
 }
 
+int pccm_tie_exposure(pccm_ctx *ctx, int dir, int normal_mode, double out[8])
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (!out) return fail(PCCM_E_ARG, "null pointer");
+    if (dir != PCCM_DIR_LEFT && dir != PCCM_DIR_RIGHT) return fail(PCCM_E_ARG, "tie exposure exists for directions 0 and 1");
+    const Cloud *it, *se;
+    NNResult *res;
+    int rc = need_nn(ctx, dir, &it, &se, &res);
+    if (rc) return rc;
+    if (normal_mode >= 0 && (rc = check_normals(ctx, *it, *se, *res, normal_mode))) return rc;
+    if ((rc = ensure_plain(ctx, *res, true))) return rc;
+    return tie_exposure(ctx, dir, *it, *se, *res, normal_mode, out);
+}
+
 int pccm_point_metric(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *out)
 {
     CHECK_CTX(ctx);

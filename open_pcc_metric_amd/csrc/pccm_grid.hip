@@ -1281,6 +1281,166 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
     return PCCM_OK;
 }
 
+// ---- tie exposure (diagnostic) ------------------------------------------------------------------------------------
+// The reference keeps whichever of several equidistant nearest neighbours nanoflann's traversal meets last
+// (cloud_pair.py:22-23: idx[-1] of a one-element search); the library keeps the smallest row (include/pccm.h).  D1 does not
+// care, the point-to-plane projection (metric.py:146-153: err = a_i - b_nn(i)) does.  For every query of the shard this kernel
+// finds ALL points of the searched cloud at exactly the nearest distance (the grid's cells inside the ball) and evaluates the
+// squared projection for each: the smallest, the largest and the library's own.  Summed over the queries they bound what ANY
+// tie rule can report as D2 MSE -- the reference's included.
+struct TieJob {
+    const void *srecs;          // cell-sorted records of the searched cloud
+    const uint32_t *cs;         // ... its cell starts
+    const double *q64;          // iterating cloud, fp64 rows
+    const double *nrm;          // searched cloud's normals, or null (counts only)
+    const int32_t *idx;         // shard's matched rows
+    const double *d2;           // ... and squared distances
+    int64_t q_begin, ns;
+    int normal_mode;
+    bool self;
+};
+
+template <typename REC>
+__global__ __launch_bounds__(256) void k_tie_exposure(TieJob J, GridGeom g, double *__restrict__ sums, unsigned long long *__restrict__ counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double vmin = 0.0, vmax = 0.0, vpick = 0.0;
+    unsigned int tied = 0, skipped = 0, mult = 0, live = 0;
+    if (i < J.ns && J.idx[i] >= 0) {
+        live = 1;
+        const int64_t row = J.q_begin + i;
+        const double qx = J.q64[3 * row], qy = J.q64[3 * row + 1], qz = J.q64[3 * row + 2];
+        const double d = J.d2[i];
+        const int pick = J.idx[i];
+        const double rad = sqrt(d) * (1.0 + 0x1.0p-40) + fmax(g.slack[0], fmax(g.slack[1], g.slack[2]));
+        const int xa = cell_coord(qx - rad, g.org[0], g.inv_h[0], g.dim[0]), xb = cell_coord(qx + rad, g.org[0], g.inv_h[0], g.dim[0]);
+        const int ya = cell_coord(qy - rad, g.org[1], g.inv_h[1], g.dim[1]), yb = cell_coord(qy + rad, g.org[1], g.inv_h[1], g.dim[1]);
+        const int za = cell_coord(qz - rad, g.org[2], g.inv_h[2], g.dim[2]), zb = cell_coord(qz + rad, g.org[2], g.inv_h[2], g.dim[2]);
+        auto value = [&](double rx, double ry, double rz, int rrow) {
+            if (!J.nrm) return 0.0;
+            const int64_t k = (J.normal_mode == PCCM_NORMAL_ROW) ? row : (int64_t)rrow;
+            const double ex = __dsub_rn(qx, rx), ey = __dsub_rn(qy, ry), ez = __dsub_rn(qz, rz);
+            double p = __dmul_rn(ex, J.nrm[3 * k]);
+            p = __fma_rn(ey, J.nrm[3 * k + 1], p);
+            p = __fma_rn(ez, J.nrm[3 * k + 2], p);
+            return __dmul_rn(p, p);
+        };
+        vmin = INFINITY;
+        vmax = -INFINITY;
+        if ((int64_t)(xb - xa + 1) * (yb - ya + 1) * (zb - za + 1) > 4096) {
+            skipped = 1;                      // an outlier's ball covers too many cells: only the library's pick is looked at
+        } else {
+            const REC *__restrict__ srecs = (const REC *)J.srecs;
+            for (int z = za; z <= zb; ++z)
+                for (int y = ya; y <= yb; ++y) {
+                    const uint32_t rowc = ((uint32_t)z * g.dim[1] + y) * g.dim[0];
+                    for (uint32_t p = J.cs[rowc + xa], e = J.cs[rowc + xb + 1]; p < e; ++p) {
+                        const P3 a = load_rec(srecs, p);
+                        if (J.self && a.row == (int)row) continue;
+                        if (gdist64(qx, qy, qz, a.x, a.y, a.z) != d) continue;
+                        const double v = value(a.x, a.y, a.z, a.row);
+                        vmin = fmin(vmin, v);
+                        vmax = fmax(vmax, v);
+                        vpick = a.row == pick ? v : vpick;
+                        ++mult;
+                    }
+                }
+        }
+        if (mult == 0) {                       // skipped, or the winner came from beyond the grid (rescan): the pick alone
+            const int64_t k = (J.normal_mode == PCCM_NORMAL_ROW) ? row : (int64_t)pick;
+            (void)k;
+            vmin = vmax = vpick = 0.0;
+            mult = 1;
+            skipped = 1;
+        }
+        tied = mult > 1 ? 1u : 0u;
+    }
+    // block totals
+    __shared__ double s_v[3][4];
+    __shared__ unsigned int s_c[4][4];
+    double a0 = live ? vmin : 0.0, a1 = live ? vmax : 0.0, a2 = vpick;
+    unsigned int c0 = live, c1 = tied, c2 = skipped, c3 = mult;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_xor(a0, off);
+        a1 += __shfl_xor(a1, off);
+        a2 += __shfl_xor(a2, off);
+        c0 += __shfl_xor(c0, off);
+        c1 += __shfl_xor(c1, off);
+        c2 += __shfl_xor(c2, off);
+        c3 = max(c3, (unsigned int)__shfl_xor((int)c3, off));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_v[0][w] = a0; s_v[1][w] = a1; s_v[2][w] = a2;
+        s_c[0][w] = c0; s_c[1][w] = c1; s_c[2][w] = c2; s_c[3][w] = c3;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // one partial per workgroup, added up on the host in workgroup order: the same on every run, and the three sums of
+        // tie-free data come out identical
+        sums[8 + 3 * (size_t)blockIdx.x + 0] = s_v[0][0] + s_v[0][1] + s_v[0][2] + s_v[0][3];
+        sums[8 + 3 * (size_t)blockIdx.x + 1] = s_v[1][0] + s_v[1][1] + s_v[1][2] + s_v[1][3];
+        sums[8 + 3 * (size_t)blockIdx.x + 2] = s_v[2][0] + s_v[2][1] + s_v[2][2] + s_v[2][3];
+        atomicAdd(&counts[0], (unsigned long long)(s_c[0][0] + s_c[0][1] + s_c[0][2] + s_c[0][3]));
+        atomicAdd(&counts[1], (unsigned long long)(s_c[1][0] + s_c[1][1] + s_c[1][2] + s_c[1][3]));
+        atomicAdd(&counts[2], (unsigned long long)(s_c[2][0] + s_c[2][1] + s_c[2][2] + s_c[2][3]));
+        atomicMax(&counts[3], (unsigned long long)max(max(s_c[3][0], s_c[3][1]), max(s_c[3][2], s_c[3][3])));
+    }
+}
+
+// out[0] queries looked at, [1] queries with two or more equidistant nearest neighbours, [2] / [3] / [4] sum over the queries
+// of the smallest / largest / the library's own squared projection, [5] queries whose ball was not enumerated, [6] the largest
+// number of equidistant nearest neighbours of one query.  res: plain columns valid (ensure_plain).
+int tie_exposure(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, const NNResult &res, int normal_mode, double out[8])
+{
+    for (int k = 0; k < 8; ++k) out[k] = 0.0;
+    const int64_t ns = res.end - res.begin;
+    if (ns <= 0) return PCCM_OK;
+    const int si = (dir == PCCM_DIR_LEFT) ? 1 : 0;
+    int rc = ensure_grid(ctx, false, 1 << si);
+    if (rc) return rc;
+    const Grid &gr = ctx->grid;
+    const GridGeom g = geom_of(gr);
+    const size_t nblk = (size_t)((ns + 255) / 256);
+    if ((rc = ensure(ctx, ctx->g_blocksum, (8 + 3 * nblk) * sizeof(double)))) return rc;
+    double *sums = (double *)ctx->g_blocksum.p;
+    unsigned long long *counts = (unsigned long long *)(sums + 4);
+    PCCM_HIP(hipMemsetAsync(sums, 0, 64, ctx->stream));
+    TieJob J;
+    J.srecs = (const char *)gr.recs.p + (size_t)(si ? gr.n[0] : 0) * (gr.rec32 ? sizeof(Rec32) : sizeof(GridRec));
+    J.cs = (const uint32_t *)gr.cell_start.p + (si ? gr.ncells + 1 : 0);
+    J.q64 = it.xyz64;
+    J.nrm = normal_mode >= 0 ? se.nrm64 : nullptr;
+    J.idx = res.idx;
+    J.d2 = res.d2;
+    J.q_begin = res.begin;
+    J.ns = ns;
+    J.normal_mode = normal_mode >= 0 ? normal_mode : PCCM_NORMAL_ROW;
+    J.self = dir == PCCM_DIR_SELF;
+    dim3 grid((unsigned)((ns + 255) / 256));
+    if (gr.rec32) hipLaunchKernelGGL((k_tie_exposure<Rec32>), grid, dim3(256), 0, ctx->stream, J, g, sums, counts);
+    else hipLaunchKernelGGL((k_tie_exposure<GridRec>), grid, dim3(256), 0, ctx->stream, J, g, sums, counts);
+    PCCM_HIP(hipGetLastError());
+    std::vector<double> hv(8 + 3 * nblk);
+    double *h = hv.data();
+    PCCM_HIP(hipMemcpyAsync(h, sums, hv.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    h[0] = h[1] = h[2] = 0.0;
+    for (size_t b = 0; b < nblk; ++b)
+        for (int k = 0; k < 3; ++k) h[k] += h[8 + 3 * b + k];
+    unsigned long long c[4];
+    for (int k = 0; k < 4; ++k) c[k] = *reinterpret_cast<const unsigned long long *>(&h[4 + k]);
+    out[0] = (double)c[0];
+    out[1] = (double)c[1];
+    out[2] = h[0];
+    out[3] = h[1];
+    out[4] = h[2];
+    out[5] = (double)c[2];
+    out[6] = (double)c[3];
+    return PCCM_OK;
+}
+
 void grid_release(pccm_ctx *ctx)
 {
     DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.occ, &ctx->grid.recs, &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum,

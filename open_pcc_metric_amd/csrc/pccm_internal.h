@@ -243,6 +243,7 @@ int spatial_order(pccm_ctx *ctx, Cloud &c);      // fills Cloud::sp (ingest; no-
 int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the current pair (cached per pair)
 int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)
 int estimate_normals(pccm_ctx *ctx, int which, int k);
+int tie_exposure(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, const NNResult &res, int normal_mode, double out[8]);
 // exact rescan of the flagged queries of njobs <= 2 results (k2b_fallback)
 int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Cloud *const *ses, NNResult *const *ress, bool self);
 

@@ -6,7 +6,8 @@
 Extra, optional flags (defaults reproduce the reference): ``--device``, ``--engine``,
 ``--normal-index row|neighbour`` (row = the reference's D2, which raises IndexError when the clouds
 differ in size), ``--extent X Y Z`` (inject the PSNR peak box instead of the
-Qhull minimal-OBB restatement).  Files without normals get them estimated on the GPU when
+Qhull minimal-OBB restatement), ``--tie-exposure`` (diagnostic on stderr: how much of the point-to-plane result hangs
+on the order of exact ties, which nanoflann decides by traversal -- cloud_pair.py:22-23).  Files without normals get them estimated on the GPU when
 --point-to-plane asks for them (k = 30 covariance normals, as Open3D's estimate_normals does at
 cloud_pair.py:61-64).  Input files: ply, pcd, xyz, xyzn, xyzrgb, pts (io.py; the formats
 ``o3d.io.read_point_cloud`` picks by extension, handler.py:57).
@@ -29,7 +30,10 @@ import click
 @click.option("--normal-index", type=click.Choice(["row", "neighbour"]), default="row", show_default=True,
               help="Which normal the point-to-plane projection uses.")
 @click.option("--extent", type=float, nargs=3, default=None, help="Extents of the PSNR peak box (skips the min-OBB).")
-def cli(ocloud, pcloud, color, hausdorff, point_to_plane, csv, device, engine, normal_index, extent) -> None:
+@click.option("--tie-exposure", is_flag=True,
+              help="After the report, print to stderr how many points have several equidistant nearest neighbours and the "
+                   "interval of point-to-plane MSE values the order of those ties can produce (diagnostic).")
+def cli(ocloud, pcloud, color, hausdorff, point_to_plane, csv, device, engine, normal_index, extent, tie_exposure) -> None:
     from .calculator import MetricCalculator
     from .cloud_pair import CloudPair
     from .io import read_point_cloud
@@ -42,3 +46,12 @@ def cli(ocloud, pcloud, color, hausdorff, point_to_plane, csv, device, engine, n
     options = CalculateOptions(color=color, hausdorff=hausdorff, point_to_plane=point_to_plane)
     result = calculator.calculate(transform_options(options)).as_df()
     print(result.to_csv() if csv else result.to_string())
+    if tie_exposure:                       # stderr: stdout stays byte-identical to the reference's report
+        for is_left in (True, False):
+            t = cloud_pair.tie_exposure(is_left, point_to_plane)
+            line = (f"tie exposure ({t['direction']}): {t['tied_queries']} of {t['queries']} points have several equidistant nearest "
+                    f"neighbours ({100.0 * t['tie_rate']:.3f} %, up to {t['max_multiplicity']})")
+            if point_to_plane:
+                line += (f"; point-to-plane mse in [{t['d2_mse_min']!r}, {t['d2_mse_max']!r}] over all tie orders, "
+                         f"reported {t['d2_mse_pick']!r} (smallest row)")
+            click.echo(line, err=True)

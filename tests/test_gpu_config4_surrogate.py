@@ -122,3 +122,32 @@ def test_config4_surrogate_cli_report_row_by_row(content, rate):
         assert txt.exit_code == 0 and txt.output == expected_text(ref, decoded[rate], csv=False)[0] + "\n"
         q1 = CliRunner().invoke(cli, ["--ocloud", ref, "--pcloud", decoded[rate], "--point-to-plane", "--extent", "1", "1", "1"])
         assert isinstance(q1.exception, IndexError)         # row-indexed normals, n_ref > n_dec (quirk Q1)
+
+
+def test_config4_surrogate_tie_exposure(content):
+    """on voxelised content the point-to-plane result depends on which of several equidistant nearest
+    neighbours is kept (the reference: nanoflann's traversal order, cloud_pair.py:22-23; here: the smallest row).  The
+    diagnostic bounds what ANY tie rule can report; the package's own value lies inside, and the CLI prints it on stderr
+    without touching the report on stdout."""
+    import open_pcc_metric_amd.metric as m
+    from open_pcc_metric_amd.calculator import MetricCalculator
+    ref, decoded, _ = content
+    a, b = read_point_cloud(ref), read_point_cloud(decoded[0])
+    with CloudPair(a, b, extent=EXTENT, normal_index="neighbour") as pair:
+        res = MetricCalculator(pair).calculate([m.GeoMSE(True, True), m.GeoMSE(False, True)]).as_dict()
+        for is_left in (True, False):
+            t = pair.tie_exposure(is_left, point_to_plane=True)
+            assert t["not_enumerated"] == 0
+            assert t["tie_rate"] > 0.05 and t["max_multiplicity"] >= 2          # integer lattice: ties are common
+            mse = float(res[("GeoMSE", is_left, True)])
+            assert t["d2_mse_min"] < t["d2_mse_max"]
+            assert t["d2_mse_min"] <= mse * (1 + 1e-12) and mse <= t["d2_mse_max"] * (1 + 1e-12)
+            assert np.isclose(mse, t["d2_mse_pick"], rtol=1e-11, atol=0)
+    # the command line: same stdout with and without the flag, the diagnostic on stderr
+    args = ["--ocloud", ref, "--pcloud", decoded[0], "--point-to-plane", "--normal-index", "neighbour", "--extent"] + [repr(x) for x in EXTENT]
+    with np.errstate(divide="ignore"):
+        plain = CliRunner().invoke(cli, args)
+        diag = CliRunner().invoke(cli, args + ["--tie-exposure"])
+    assert plain.exit_code == 0 and diag.exit_code == 0
+    assert diag.stdout == plain.stdout
+    assert diag.stderr.count("tie exposure (") == 2 and "point-to-plane mse in [" in diag.stderr
