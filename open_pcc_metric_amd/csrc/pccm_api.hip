@@ -797,7 +797,7 @@ static int ensure_plain(pccm_ctx *ctx, NNResult &res, bool need_idx)
 {
     if (res.plain_valid || (!need_idx && res.plain_d2_valid)) return PCCM_OK;
     if (!res.rec_valid) return fail(PCCM_E_STATE, "no nearest-neighbour result to read");
-    if (need_idx && res.rec_stride != 4) {
+    if (need_idx && res.rec_stride != 4 && res.rec_layout != 1) {      // (matched records always carry the row)
         // the search ran without the matched rows (pccm_nn_want_idx off) and now somebody asks for them: run it again
         // for this direction with the rows on -- same results, 32-byte records; the clouds and the grid are resident
         if (ctx->capturing) {
@@ -808,10 +808,14 @@ static int ensure_plain(pccm_ctx *ctx, NNResult &res, bool need_idx)
         int rc = nn_grid(ctx, 1, &dir, /*force_idx=*/1);
         if (rc) return rc;
     }
-    int rc = launch_unpack(ctx, (const double *)res.rec.p, res.rec_stride, res.end - res.begin, res.idx, res.d2);
+    const bool rows = res.rec_stride == 4 || res.rec_layout == 1;
+    const int udir = (int)(&res - ctx->nn);
+    const Cloud &uit = ctx->cloud[udir == PCCM_DIR_RIGHT ? 1 : 0];
+    int rc = launch_unpack(ctx, (const double *)res.rec.p, res.rec_stride, res.rec_layout, (const float *)uit.xyz32, res.begin, res.end - res.begin,
+                           rows ? res.idx : nullptr, res.d2);
     if (rc) return rc;
     res.plain_d2_valid = true;
-    res.plain_valid = res.rec_stride == 4;
+    res.plain_valid = rows;
     return PCCM_OK;
 }
 
@@ -971,11 +975,12 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
     // where the column lives: a field of the grid engine's 32-byte result records (squared distance, or the signed
     // projection fused into the search by pccm_nn_fuse), or a plain column (brute-force engine; unfused projection)
     const double *dev = nullptr;
-    int stride = 1, square = 0;
+    int stride = 1, square = 0, defer = 0;
     if (metric == PCCM_METRIC_D1) {
         if (res->rec_valid) {
             dev = (const double *)res->rec.p;
             stride = res->rec_stride;
+            if (res->rec_layout == 1) defer = 3;             // matched records: the reduction forms the distance (NNOut::layout)
         } else {
             if ((rc = ensure_plain(ctx, *res, false))) return rc;
             dev = res->d2;
@@ -984,10 +989,11 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         if (metric != PCCM_METRIC_D2 && metric != PCCM_METRIC_PROJ) return fail(PCCM_E_ARG, "bad metric %d", metric);
         if (dir == PCCM_DIR_SELF) return fail(PCCM_E_ARG, "point-to-plane is not defined for the self search");
         if ((rc = check_normals(ctx, *it, *se, *res, normal_mode))) return rc;
-        if (res->rec_valid && res->fused_mode == normal_mode) {
+        if (res->rec_valid && (res->fused_mode == normal_mode || (res->rec_layout == 1 && normal_mode == PCCM_NORMAL_ROW))) {
             dev = (const double *)res->rec.p + 1;
             stride = res->rec_stride;
             square = metric == PCCM_METRIC_D2 ? 1 : 0;       // metric.py:179: the square of the stored projection
+            if (res->rec_layout == 1) defer = se->nrm_exact32 ? 1 : 2;   // ... which this reduction forms itself (NNOut::layout)
         } else {
             if ((rc = ensure_plain(ctx, *res))) return rc;
             if ((rc = ensure(ctx, s.val, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
@@ -1044,10 +1050,12 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         if (host_job) {
             host_job->c[1] = col;
             host_job->ncols = 2;
+            if (defer && (host_job->defer == 0 || host_job->defer == 3)) host_job->defer = defer;   // (3: distances only so far)
         } else {
             if (uj.njobs >= 8) return fail(PCCM_E_ARG, "too many columns in one reduction batch");
             UnitJob &U = uj.j[uj.njobs];
             U.val = base; U.stride = stride; U.ncols = 1;
+            U.defer = defer; U.nrm64 = se->nrm64; U.nrm32 = se->nrm32; U.q32 = (const float *)it->xyz32; U.row0 = res->begin;
             U.c[0] = col; U.c[1] = col;
             U.ns = ns; U.nunits = s.nunits;
             U.tail_first = s.t0 - res->begin; U.tail_n = s.tail_n;
@@ -1120,7 +1128,7 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
         if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
         if (metrics[k] == PCCM_METRIC_D1 || dirs[k] == PCCM_DIR_SELF) continue;
         NNResult &res = ctx->nn[dirs[k]];
-        if (!res.valid || !res.rec_valid || res.fused_mode == normal_modes[k] || res.rec_stride == 4) continue;
+        if (!res.valid || !res.rec_valid || res.fused_mode == normal_modes[k] || res.rec_stride == 4 || res.rec_layout == 1) continue;
         if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k], want_units)) continue;
         int rc = ensure_plain(ctx, res, true);
         if (rc) return rc;
@@ -1450,6 +1458,7 @@ static int graph_replay(pccm_ctx *ctx, GraphRec &g)
             ctx->nn[op.dir].plain_valid = op.plain_valid;
             ctx->nn[op.dir].fused_mode = op.fused_mode;
             ctx->nn[op.dir].rec_stride = op.rec_stride;
+            ctx->nn[op.dir].rec_layout = op.rec_layout;
             ctx->nn[op.dir].plain_d2_valid = op.plain_valid;
         } else if (op.kind == 2) {
             ReduceSlot &s = ctx->slots[op.slot];
@@ -1514,6 +1523,7 @@ int pccm_graph_end(pccm_ctx *ctx, int *graph_id)
             op.plain_valid = ctx->nn[op.dir].plain_valid;
             op.fused_mode = ctx->nn[op.dir].fused_mode;
             op.rec_stride = ctx->nn[op.dir].rec_stride;
+            op.rec_layout = ctx->nn[op.dir].rec_layout;
         }
     g.epoch = ctx->epoch;
     g.valid = true;

@@ -218,7 +218,9 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
     // the first query record of the job instead): a conditional one ends in register copies behind the load, i.e. the same wait.
     double n0 = 0.0, n1 = 0.0, n2 = 0.0;
     float4 nraw = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool defer = out.layout == 1;             // the reduction forms err . normal[row]: no normal is read here (NNOut::layout)
     auto gather_row_normal = [&](int row, bool on) {
+        if (defer) return;
         if (N32) {
             const float4 *src = on ? out.nrm32 + row : reinterpret_cast<const float4 *>(qbase);
             nraw = *src;
@@ -422,7 +424,9 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
             const int wrow = __float_as_int(c[6]);
             const double d64 = gdist64(qx, qy, qz, rx, ry, rz);
             settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
-            if (settled) {
+            if (settled && defer) {
+                store_result_rec(out, qrow, c[0], c[2], c[4], wrow);        // the matched record as it lies in LDS: one 16-byte store
+            } else if (settled) {
                 double p = 0.0;
                 if (fuse) {
                     double e0 = N32 ? (double)nraw.x : n0, e1 = N32 ? (double)nraw.y : n1, e2 = N32 ? (double)nraw.z : n2;

@@ -326,6 +326,12 @@ __device__ __forceinline__ void rescan_emit(const RescanJob &J, int64_t i, int b
         J.d2_out[i] = bd;
         return;
     }
+    if (J.rec_layout == 1) {                        // the matched record: the reduction forms distance and projection (NNOut::layout)
+        const bool has = bj >= 0 && bj != 0x7fffffff;
+        const double *src = has ? J.r64 + 3 * (int64_t)bj : J.q64 + 3 * (J.q_begin + i);
+        reinterpret_cast<float4 *>(J.rec_out)[i] = make_float4((float)src[0], (float)src[1], (float)src[2], __int_as_float(has ? bj : -1));
+        return;
+    }
     double p = 0.0;
     if (J.nrm && bj >= 0 && bj != 0x7fffffff) {
         const int64_t gi = J.q_begin + i, k = (J.normal_mode == PCCM_NORMAL_ROW) ? gi : (int64_t)bj;
@@ -444,6 +450,7 @@ int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Clo
         // the grid engine's results are 32-byte records (nn_grid set rec_valid for this run); the brute engine writes columns
         J.rec_out = res.rec_valid ? (double *)res.rec.p : nullptr;
         J.rec_stride = res.rec_stride;
+        J.rec_layout = res.rec_valid ? res.rec_layout : 0;
         J.nrm = (res.rec_valid && res.fused_mode >= 0) ? se.nrm64 : nullptr;
         J.normal_mode = res.fused_mode >= 0 ? res.fused_mode : PCCM_NORMAL_ROW;
         J.part_d = (double *)ctx->rescan_part.p + (size_t)k * kSplitMax * cap;

@@ -139,7 +139,19 @@ struct NNOut {
     const float4 *nrm32;   // the same normals as aligned 16-byte words when they are fp32-exact (the brick kernel's gather), or null
     int64_t row_base;
     int normal_mode;       // PCCM_NORMAL_ROW / PCCM_NORMAL_NEIGHBOUR
+    int layout;            // 0: {d2, projection[, row, -]}; 1: the MATCHED RECORD itself, {rx, ry, rz (fp32), row} = 16 bytes (stride 2
+                           //    doubles; Rec32 grids: the fp32 coordinates are exact).  Squared distance and row-indexed
+                           //    projection are formed by the reduction that reads the records, from the iterating cloud's rows
+                           //    and the searched cloud's normals -- both read in row order there, i.e. coalesced -- with the
+                           //    search's own expressions, bit for bit.  No search kernel gathers a normal (round 2's brick
+                           //    kernel: 2 M random 16-byte reads per launch), a result is one 16-byte store, and the matched
+                           //    row always comes along.
 };
+
+__device__ __forceinline__ void store_result_rec(const NNOut &o, int qrow, float rx, float ry, float rz, int wrow)
+{
+    reinterpret_cast<float4 *>(o.rec)[qrow - o.row_base] = make_float4(rx, ry, rz, __int_as_float(wrow));
+}
 
 __device__ __forceinline__ void store_result(const NNOut &o, int qrow, double d2, double p, int wrow)
 {
@@ -151,6 +163,11 @@ __device__ __forceinline__ void store_result(const NNOut &o, int qrow, double d2
 __device__ __forceinline__ void emit_result(const NNOut &o, int qrow, double qx, double qy, double qz, int wrow, double d2,
                                             double rx, double ry, double rz)
 {
+    if (o.layout == 1) {                        // (no neighbour -- a self search on a one-point cloud: the point itself, d2 = 0)
+        const bool has = wrow >= 0;
+        store_result_rec(o, qrow, (float)(has ? rx : qx), (float)(has ? ry : qy), (float)(has ? rz : qz), wrow);
+        return;
+    }
     double p = 0.0;
     if (o.nrm && wrow >= 0) {
         // metric.py:146-153: err . normal_other[row]; FMA chain as np.dot evaluates it (see pccm_point.hip, K3)
@@ -169,7 +186,7 @@ __device__ __forceinline__ void emit_result_lookup(const NNOut &o, const double 
                                                    double qz, int wrow, double d2)
 {
     double rx = 0.0, ry = 0.0, rz = 0.0;
-    if (o.nrm && wrow >= 0) {
+    if ((o.nrm || o.layout == 1) && wrow >= 0) {
         rx = s64[3 * (int64_t)wrow];
         ry = s64[3 * (int64_t)wrow + 1];
         rz = s64[3 * (int64_t)wrow + 2];

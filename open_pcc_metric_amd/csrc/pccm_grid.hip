@@ -1167,6 +1167,13 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         J.slack32 = exact ? 0.0 : maxabs * 0x1.0p-20;
         const int fm = fused_mode(ctx, dir, it, se);
         res.rec_stride = (ctx->want_idx || force_idx) ? 4 : 2;
+        // fp32-exact pairs, and no neighbour-indexed projection to fuse: the searches leave the matched record itself (16 bytes,
+        // one store) and the reductions form distance and row-indexed projection from rows and normals they read in row order
+        // (NNOut::layout).  PCCM_DEFER=0: the searches form both themselves, as in round 2 (A/B runs)
+        static const bool defer_off = [] { const char *e = getenv("PCCM_DEFER"); return e && e[0] == '0'; }();
+        const bool defer = !defer_off && gr.rec32 && fm != PCCM_NORMAL_NEIGHBOUR;
+        if (defer) res.rec_stride = 2;
+        res.rec_layout = defer ? 1 : 0;
         J.out.rec = (double *)res.rec.p;
         J.out.stride = res.rec_stride;
         J.out.nrm = fm >= 0 ? se.nrm64 : nullptr;
@@ -1174,6 +1181,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         J.out.nrm32 = (fm >= 0 && se.nrm_exact32 && !nrm32_off) ? se.nrm32 : nullptr;
         J.out.row_base = res.begin;
         J.out.normal_mode = fm >= 0 ? fm : PCCM_NORMAL_ROW;
+        J.out.layout = res.rec_layout;
         res.fused_mode = fm;
         res.rec_valid = true;
         res.plain_valid = res.plain_d2_valid = false;

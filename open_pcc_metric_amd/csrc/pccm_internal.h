@@ -68,6 +68,8 @@ struct NNResult {
     bool plain_d2_valid = false;   // d2 alone does (unpacked from records that carry no row)
     int fused_mode = -1;        // normal mode of the projection stored in `rec`, -1: not fused
     int rec_stride = 4;         // doubles per record: 4 = with the matched row, 2 = {d2, projection} only (pccm_nn_want_idx off)
+    int rec_layout = 0;         // 0: {d2, projection[, row, -]}; 1 (stride 2): the matched record {rx, ry, rz, row}: distance and
+                                //    row-indexed projection are formed by the reduction that reads the records (NNOut::layout)
     int64_t stats[3] = {0, 0, 0};
     uint32_t *nflag_dev = nullptr;  // device counters of the last run: [0] fallback queries, [1] grid tail length
     DevBuf flagged, flag_thr;       // queries handed to the exact rescan (k2b_fallback) and their thresholds
@@ -148,7 +150,7 @@ struct GraphOp {               // host-side effect of one captured call, replaye
     int kind = 0;              // 0 drop_caches, 1 nn(dir), 2 reduce_prefetch(slot)
     int dir = 0, slot = -1;
     bool rec_valid = false, plain_valid = false;   // kind 1: where the direction's results live once the graph has run
-    int fused_mode = -1, rec_stride = 4;
+    int fused_mode = -1, rec_stride = 4, rec_layout = 0;
     ReduceSlot snap;           // kind 2: the slot's bookkeeping at capture time (pointers are not owned)
 };
 
@@ -259,6 +261,7 @@ struct RescanJob {              // flagged queries of one result (k2b_fallback)
     double *d2_out;
     double *rec_out;            // ... or result records with the projection fused (grid engine), when non-null
     int rec_stride;             // doubles per record (NNResult::rec_stride)
+    int rec_layout;             // NNResult::rec_layout
     const double *nrm;          // normals for the fused projection, or null
     int normal_mode;
     double *part_d;             // split regime: [kSplitMax][gridDim.x] partial minima
@@ -292,6 +295,14 @@ struct UnitCol {                // one column reduced from a job's array
 struct UnitJob {                // one per-point array to reduce (k_unit_jobs): up to two columns per pass
     const double *val;          // plain column (stride 1) or the result records (stride 2 or 4 doubles)
     int stride;
+    // records of layout 1 (the matched record {rx, ry, rz, row}, 16 bytes): field 0 = the squared distance to row row0 + i of the
+    // iterating cloud (q32), field 1 = err . normal[row0 + i] (metric.py:146-153), both formed here -- the rows and the searched
+    // cloud's row-indexed normals are read in row order, i.e. coalesced, where the search would have gathered the normal
+    int defer;                  // 0: no; 1: normals as 16-byte fp32-exact words (nrm32); 2: as fp64 rows (nrm64); 3: no normals (field 0 only)
+    const double *nrm64;
+    const float4 *nrm32;
+    const float *q32;           // iterating cloud, fp32 quads layout (Cloud::xyz32)
+    int64_t row0;               // row of the cloud the shard's first record belongs to
     int ncols;
     UnitCol c[2];
     int64_t ns, nunits;
@@ -305,7 +316,8 @@ struct UnitJobs {
     int64_t toff[9];            // prefix sums of tail_n
 };
 int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs);
-int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int64_t ns, int32_t *idx, double *d2);   // result records -> plain columns
+// result records -> plain columns (q32 / row0: the iterating cloud's rows, for records of layout 1)
+int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int layout, const float *q32, int64_t row0, int64_t ns, int32_t *idx, double *d2);
 int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs);
 
 int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,

@@ -242,7 +242,37 @@ int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs)
 struct UnitView {               // the fields of a job the inner loop needs, in registers (wave-uniform)
     const double *val;
     int stride, off0, off1, sq0, sq1;
+    int defer;                  // UnitJob::defer
+    const double *nrm64;
+    const float4 *nrm32;
+    const float *q32;
+    int64_t row0;
 };
+
+// The two fields of a result record of layout 1 (the matched record {rx, ry, rz, row}, NNOut::layout) for row `row` of the
+// iterating cloud: squared distance -- nanoflann's accumulation order, as every search kernel evaluates it (gdist64, pccm_grid.h)
+// -- and err . normal[row] -- the FMA chain of emit_result / K3; bit for bit what the searches would have stored.
+__device__ __forceinline__ void matched_fields(const float4 rec, const float *__restrict__ q32, int defer, const double *__restrict__ nrm64,
+                                               const float4 *__restrict__ nrm32, int64_t row, bool want_proj, double &d2, double &proj)
+{
+    const float *q = q32 + (row >> 2) * 12 + (row & 3);
+    const double qx = (double)q[0], qy = (double)q[4], qz = (double)q[8];
+    const double ex = __dsub_rn(qx, (double)rec.x), ey = __dsub_rn(qy, (double)rec.y), ez = __dsub_rn(qz, (double)rec.z);
+    d2 = __dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez));
+    proj = 0.0;
+    if (want_proj && defer != 3) {
+        double n0, n1, n2;
+        if (defer == 1) {
+            const float4 t = nrm32[row];
+            n0 = (double)t.x; n1 = (double)t.y; n2 = (double)t.z;
+        } else {
+            n0 = nrm64[3 * row]; n1 = nrm64[3 * row + 1]; n2 = nrm64[3 * row + 2];
+        }
+        proj = __dmul_rn(ex, n0);
+        proj = __fma_rn(ey, n1, proj);
+        proj = __fma_rn(ez, n2, proj);
+    }
+}
 
 __device__ __forceinline__ UnitView unit_view(const UnitJob &J)
 {
@@ -251,12 +281,15 @@ __device__ __forceinline__ UnitView unit_view(const UnitJob &J)
     w.stride = J.stride;
     w.off0 = J.c[0].off; w.off1 = J.c[1].off;
     w.sq0 = J.c[0].square; w.sq1 = J.c[1].square;
+    w.defer = J.defer; w.nrm64 = J.nrm64; w.nrm32 = J.nrm32; w.q32 = J.q32; w.row0 = J.row0;
     return w;
 }
 
 __device__ __forceinline__ void unit_load(const UnitView &J, int64_t i, double v[2])      // the load alone (callers batch them)
 {
-    if (J.stride >= 2) {
+    if (J.stride >= 2 && J.defer) {
+        matched_fields(reinterpret_cast<const float4 *>(J.val)[i], J.q32, J.defer, J.nrm64, J.nrm32, J.row0 + i, true, v[0], v[1]);
+    } else if (J.stride >= 2) {
         const double2 t = *reinterpret_cast<const double2 *>(&J.val[i * J.stride]);
         v[0] = t.x;
         v[1] = t.y;
@@ -299,7 +332,10 @@ __global__ __launch_bounds__(256) void k_unit_jobs(UnitJobs jobs)
         if (cnt == kLeaf) {
             double v[kLeaf / 8][2];
             // sixteen independent loads first; the layout test sits outside the loop so that they are issued together
-            if (V.stride >= 2) {
+            if (V.stride >= 2 && V.defer) {
+#pragma unroll
+                for (int j = 0; j < kLeaf / 8; ++j) unit_load(V, base + 8 * j + k, v[j]);
+            } else if (V.stride >= 2) {
 #pragma unroll
                 for (int j = 0; j < kLeaf / 8; ++j) {
                     const double2 t = *reinterpret_cast<const double2 *>(&V.val[(base + 8 * j + k) * V.stride]);
@@ -418,7 +454,7 @@ __device__ __forceinline__ double dmax_raw(double a, double b)
     return r;
 }
 
-template <int STRIDE, int CFG>
+template <int STRIDE, int CFG, int DEFER = 0>      // DEFER: UnitJob::defer of every job (records of layout 1; STRIDE 2)
 __global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
 {
     constexpr int NC = CFG == 0 ? 2 : 1;
@@ -439,9 +475,20 @@ __global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
         const bool live = u < nunits;
         const int64_t cnt = !live ? 0 : ((ns - base < kLeaf) ? ns - base : kLeaf);
         double r[NC], mn[NC], mx[NC];
-        // column values of one record
-        auto cols = [](const double *p, double out[NC]) {
-            if (STRIDE >= 2) {
+        // column values of one record (e: its index in the shard)
+        const double *__restrict__ nrm64 = J.nrm64;
+        const float4 *__restrict__ nrm32 = J.nrm32;
+        const float *__restrict__ q32 = J.q32;
+        const int64_t row0 = J.row0;
+        auto cols = [&](const double *p, int64_t e, double out[NC]) {
+            if (DEFER) {
+                double x, y;
+                matched_fields(*reinterpret_cast<const float4 *>(p), q32, DEFER, nrm64, nrm32, row0 + e, CFG != 1, x, y);
+                if (CFG == 0) { out[0] = x; out[1] = __dmul_rn(y, y); }
+                else if (CFG == 1) out[0] = x;
+                else if (CFG == 2) out[0] = __dmul_rn(y, y);
+                else out[0] = y;
+            } else if (STRIDE >= 2) {
                 const double2 q = *reinterpret_cast<const double2 *>(p);
                 if (CFG == 0) { out[0] = q.x; out[1] = __dmul_rn(q.y, q.y); }
                 else if (CFG == 1) out[0] = q.x;
@@ -455,7 +502,7 @@ __global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
             const double *p = val + (base + k) * STRIDE;
             double v[kLeaf / 8][NC];
 #pragma unroll
-            for (int j = 0; j < kLeaf / 8; ++j) cols(p + (int64_t)j * 8 * STRIDE, v[j]);
+            for (int j = 0; j < kLeaf / 8; ++j) cols(p + (int64_t)j * 8 * STRIDE, base + k + 8 * j, v[j]);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 r[c] = v[0][c];
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
             for (int c = 0; c < NC; ++c) { r[c] = 0.0; mn[c] = INFINITY; mx[c] = -INFINITY; }
             for (int64_t e = k; e < cnt; e += 8) {
                 double w[NC];
-                cols(val + (base + e) * STRIDE, w);
+                cols(val + (base + e) * STRIDE, base + e, w);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     r[c] = __dadd_rn(r[c], w[c]);
@@ -536,7 +583,14 @@ __global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
     const int64_t e = c0 - jobs.toff[jb];
     const double *p = J.val + (J.tail_first + e) * STRIDE;
     double w[NC];
-    if (STRIDE >= 2) {
+    if (DEFER) {
+        double x, y;
+        matched_fields(*reinterpret_cast<const float4 *>(p), J.q32, DEFER, J.nrm64, J.nrm32, J.row0 + J.tail_first + e, CFG != 1, x, y);
+        if (CFG == 0) { w[0] = x; w[1] = __dmul_rn(y, y); }
+        else if (CFG == 1) w[0] = x;
+        else if (CFG == 2) w[0] = __dmul_rn(y, y);
+        else w[0] = y;
+    } else if (STRIDE >= 2) {
         const double2 q = *reinterpret_cast<const double2 *>(p);
         if (CFG == 0) { w[0] = q.x; w[1] = __dmul_rn(q.y, q.y); }
         else if (CFG == 1) w[0] = q.x;
@@ -561,7 +615,8 @@ static int lean_shape(const UnitJobs &jobs)
         else if (J.c[0].off == 0) cfg = J.c[0].square ? -1 : 1;
         else cfg = J.c[0].square ? 2 : 3;
         if (cfg < 0 || (J.stride != 1 && J.stride != 2 && J.stride != 4)) return -1;
-        const int sh = J.stride * 4 + cfg;
+        if (J.defer && J.stride != 2) return -1;
+        const int sh = J.stride * 4 + cfg + 64 * J.defer;
         if (shape >= 0 && sh != shape) return -1;
         shape = sh;
     }
@@ -583,6 +638,13 @@ int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
     case 4 * 4 + 0: hipLaunchKernelGGL((k_unit_lean<4, 0>), grid, block, 0, ctx->stream, jobs); break;
     case 4 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<4, 1>), grid, block, 0, ctx->stream, jobs); break;
     case 4 * 4 + 2: hipLaunchKernelGGL((k_unit_lean<4, 2>), grid, block, 0, ctx->stream, jobs); break;
+    case 64 + 2 * 4 + 0: hipLaunchKernelGGL((k_unit_lean<2, 0, 1>), grid, block, 0, ctx->stream, jobs); break;      // matched records, fp32-exact normals
+    case 64 + 2 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<2, 1, 1>), grid, block, 0, ctx->stream, jobs); break;
+    case 64 + 2 * 4 + 2: hipLaunchKernelGGL((k_unit_lean<2, 2, 1>), grid, block, 0, ctx->stream, jobs); break;
+    case 128 + 2 * 4 + 0: hipLaunchKernelGGL((k_unit_lean<2, 0, 2>), grid, block, 0, ctx->stream, jobs); break;     // ... fp64 normals
+    case 128 + 2 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<2, 1, 2>), grid, block, 0, ctx->stream, jobs); break;
+    case 128 + 2 * 4 + 2: hipLaunchKernelGGL((k_unit_lean<2, 2, 2>), grid, block, 0, ctx->stream, jobs); break;
+    case 192 + 2 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<2, 1, 3>), grid, block, 0, ctx->stream, jobs); break;     // ... no normals: distances only
     default: hipLaunchKernelGGL(k_unit_jobs, grid, block, 0, ctx->stream, jobs); break;      // mixed shapes; signed projections (min / max of -0.0 and 0.0: fmin / fmax there)
     }
     PCCM_HIP(hipGetLastError());
@@ -590,20 +652,28 @@ int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
 }
 
 // Result records -> plain columns (only when a consumer wants them: colour kernels, getters, pccm_nn_fetch).
-__global__ __launch_bounds__(256) void k_unpack(const double *__restrict__ rec, int stride, int64_t ns, int32_t *__restrict__ idx,
-                                                double *__restrict__ d2)
+__global__ __launch_bounds__(256) void k_unpack(const double *__restrict__ rec, int stride, int layout, const float *__restrict__ q32, int64_t row0,
+                                                int64_t ns, int32_t *__restrict__ idx, double *__restrict__ d2)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ns) return;
+    if (layout == 1) {                                     // the matched record: {rx, ry, rz, row}
+        const float4 r = reinterpret_cast<const float4 *>(rec)[i];
+        double x, y;
+        matched_fields(r, q32, 3, nullptr, nullptr, row0 + i, false, x, y);
+        if (idx) idx[i] = __float_as_int(r.w);
+        d2[i] = x;
+        return;
+    }
     const double *r = rec + i * stride;
-    if (stride == 4) idx[i] = (int32_t)(__double_as_longlong(r[2]) & 0xffffffffll);      // 16-byte records carry no row
+    if (stride == 4 && idx) idx[i] = (int32_t)(__double_as_longlong(r[2]) & 0xffffffffll);      // 16-byte records carry no row
     d2[i] = r[0];
 }
 
-int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int64_t ns, int32_t *idx, double *d2)
+int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int layout, const float *q32, int64_t row0, int64_t ns, int32_t *idx, double *d2)
 {
     if (ns <= 0) return PCCM_OK;
-    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rec, stride, ns, idx, d2);
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rec, stride, layout, q32, row0, ns, idx, d2);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
