@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == f32-MFMA dense peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec peak
 FLOP_PER_PAIR = 8            # 3 sub + 1 mul + 2 fma
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def synth(n):
@@ -331,22 +331,36 @@ def main():
     elif gq_n:
         avg_ms = gq_ms / gq_n
         ncells = float(stats[0]["splits"])      # grid engine: pccm_nn_stats reports the cells of the grid it searched
-        # one launch serves BOTH directions (pccm_nn_pair).  DESIGN.md section 3, per direction and query:
-        # its 16-byte record in, the row-indexed normal (24 B) in, ONE 16-byte result record (d2, projection; the matched
-        # row is left out when nothing will read it: pccm_nn_want_idx) out = 56 B/query; per searched point its 16-byte
-        # record once; cell starts of both clouds, 4 B/cell each
-        alg_bytes = 2.0 * (56.0 * q_rows + 16.0 * n + 8.0 * ncells)
-        # SURVEY.md section 8(d)'s layout-independent compulsory bytes: 12 (N_q + N_r) + 24 N_q, + 12 N normals
+        # one launch serves BOTH directions (pccm_nn_pair).  DESIGN.md section 3, per direction: a query's 16-byte record in,
+        # ONE 16-byte result out (the matched record: squared distance and row-indexed projection are formed by the reduction,
+        # which reads rows and normals in row order -- round 3; round 2 gathered a 16/24-byte normal per query here and
+        # stored {d2, projection}); per searched point its 16-byte record once; cell starts of both clouds, 4 B/cell each
+        alg_bytes = 2.0 * (32.0 * q_rows + 16.0 * n + 8.0 * ncells)
+        # SURVEY.md section 8(d)'s layout-independent compulsory bytes of search + projection: 12 (N_q + N_r) + 24 N_q, + 12 N
+        # normals -- kept as the yardstick of `frac_compulsory` although 12 N_q of normals and 8 of the 24 output bytes now
+        # belong to the reduction's pass (its own figure: `reduce_roofline`)
         compulsory = 2.0 * (12.0 * (q_rows + n) + 24.0 * q_rows + 12.0 * q_rows)
         traffic, traffic_note = committed_traffic("k_brick_query", n, world)
         roofline = {"bound": "hbm", "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "frac_compulsory": round(compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "traffic": traffic,
-                    "kernel": "k_brick_query (ring-1 search of both directions + fused D2 projection, one launch)",
+                    "kernel": "k_brick_query (ring-1 search of both directions, one launch; results = matched records)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": gq_n, "algorithmic_bytes_per_launch": alg_bytes,
                     "compulsory_bytes_per_launch": compulsory, "traffic_note": traffic_note,
                     "arithmetic": "fp32 candidate filter in LDS, fp64 decisions and outputs"}
+
+    reduce_roofline = None
+    red_ms, red_n = eng.profile_get("reduce")
+    if gq_n and red_n:
+        # the reductions' pass over matched records: per row of either cloud its 16-byte result record, its own 16-byte coordinate
+        # word and the other cloud's row-indexed normal (16 bytes) -- all streamed in row order
+        rbytes = 2.0 * q_rows * 48.0
+        reduce_roofline = {"bound": "hbm", "achieved": round(rbytes / (red_ms / red_n * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(rbytes / (red_ms / red_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "avg_launch_ms": round(red_ms / red_n, 4),
+                           "algorithmic_bytes_per_launch": rbytes,
+                           "kernel": "k_unit_lean (distance + row-indexed projection from matched records, NumPy-order sums and extrema of "
+                                     "the D1 and D2 columns of both directions)"}
 
     line = {
         "metric": "Mpoints/s for symmetric D1+D2 PSNR, N_ref=N_deg=%s" % (f"{n // 1_000_000}M" if n % 1_000_000 == 0 else n),
@@ -360,7 +374,7 @@ def main():
                    "fallback_queries": [s["fallback_queries"] for s in stats],
                    ("grid_cells" if gq_n else "scan_splits"): [s["splits"] for s in stats]},
         "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (args.backend if world > 1 else None),
-        "roofline": roofline, "roofline_measured_by": prof_leg,
+        "roofline": roofline, "roofline_measured_by": prof_leg, "reduce_roofline": reduce_roofline,
         "kernel_us_per_step": {k: round(v[0] / prof_steps * 1e3, 1) for k, v in prof.items() if v[1]},
         "result_sample": {"GeoMSE_sym_d1": float(result[("SymmetricMetric", "GeoMSE", True, False, "GeoMSE", False, False)]),
                           "GeoPSNR_sym_d2": float(result[("SymmetricMetric", "GeoPSNR", True, True, "GeoPSNR", False, True)])},
@@ -412,8 +426,21 @@ def main():
             with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine) as fresh:
                 MetricCalculator(fresh).calculate(headline_metrics()).as_dict()
         dt = (time.perf_counter() - t_e2e) / reps
+        h2d_bytes = a.nbytes + b.nbytes + na.nbytes + nb.nbytes
+        # the upload alone, same buffers, same context: what PCIe and the pageable-memory path allow
+        ue = nat.Engine(local)
+        ue.set_cloud(0, a); ue.set_normals(0, na); ue.set_cloud(1, b); ue.set_normals(1, nb); ue.sync()
+        t_up = time.perf_counter()
+        for _ in range(reps):
+            ue.set_cloud(0, a); ue.set_normals(0, na); ue.set_cloud(1, b); ue.set_normals(1, nb)
+        ue.sync()
+        up = (time.perf_counter() - t_up) / reps
+        ue.close()
         line["end_to_end"] = {"ms_per_pair": round(dt * 1e3, 4), "value": round(2 * n / dt / 1e6, 2), "unit": "Mpoints/s",
-                              "note": "fresh CloudPair per iteration: H2D of 2 clouds + 2 normal sets (pageable), ingest, sweeps, report"}
+                              "h2d_ms": round(up * 1e3, 4), "h2d_bytes": int(h2d_bytes), "h2d_GBs": round(h2d_bytes / up / 1e9, 1),
+                              "note": "fresh CloudPair per iteration: H2D of 2 clouds + 2 normal sets (pageable fp32, 48 MB), ingest incl. the "
+                                      "spatial ordering of both clouds, sweeps, report; h2d_ms = the four uploads + ingests alone (PCIe "
+                                      "Gen5 x16: 63 GB/s spec -> 0.76 ms for these bytes at best)"}
 
         # (3) a cold pair: brand-new context (no pooled allocations), nothing inherited from an earlier pair
         # (PCCM_GRID_NO_REUSE=1: the cell-edge decision with its histogram passes and host round trips runs), one report

@@ -112,6 +112,9 @@ static void free_cloud(Cloud &c)
 {
     if (c.xyz32) (void)hipFree(c.xyz32);
     if (c.xyz64) (void)hipFree(c.xyz64);
+    if (c.xyz32r) (void)hipFree(c.xyz32r);
+    c.xyz32r = nullptr;
+    c.cap32r = 0;
     if (c.nrm64) (void)hipFree(c.nrm64);
     if (c.nrm32) (void)hipFree(c.nrm32);
     if (c.rgb64) (void)hipFree(c.rgb64);
@@ -317,6 +320,7 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     const int64_t n_pad = (n + kScanTile - 1) / kScanTile * kScanTile;
     int rc = grow((void **)&c.xyz32, c.cap32, (size_t)n_pad * 3 * sizeof(float));
     if (!rc) rc = grow((void **)&c.xyz64, c.cap64, (size_t)n * 3 * sizeof(double));
+    if (!rc) rc = grow((void **)&c.xyz32r, c.cap32r, (size_t)n * sizeof(float4));
     if (rc) return rc;
     const size_t esz = dtype == PCCM_F32 ? 4 : 8;
     const void *dsrc = nullptr;
@@ -325,7 +329,7 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     unsigned long long *stats = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(stats, 0, 10 * sizeof(unsigned long long), ctx->stream));
     PCCM_HIP(hipMemsetAsync(stats + 3, 0xff, 3 * sizeof(unsigned long long), ctx->stream));
-    rc = launch_ingest_points(ctx, dsrc, dtype, n, n_pad, c.xyz32, c.xyz64, stats);
+    rc = launch_ingest_points(ctx, dsrc, dtype, n, n_pad, c.xyz32, c.xyz64, c.xyz32r, stats);
     if (rc) return rc;
     unsigned long long h[10];
     PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -811,7 +815,7 @@ static int ensure_plain(pccm_ctx *ctx, NNResult &res, bool need_idx)
     const bool rows = res.rec_stride == 4 || res.rec_layout == 1;
     const int udir = (int)(&res - ctx->nn);
     const Cloud &uit = ctx->cloud[udir == PCCM_DIR_RIGHT ? 1 : 0];
-    int rc = launch_unpack(ctx, (const double *)res.rec.p, res.rec_stride, res.rec_layout, (const float *)uit.xyz32, res.begin, res.end - res.begin,
+    int rc = launch_unpack(ctx, (const double *)res.rec.p, res.rec_stride, res.rec_layout, uit.xyz32r, res.begin, res.end - res.begin,
                            rows ? res.idx : nullptr, res.d2);
     if (rc) return rc;
     res.plain_d2_valid = true;
@@ -1055,7 +1059,7 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
             if (uj.njobs >= 8) return fail(PCCM_E_ARG, "too many columns in one reduction batch");
             UnitJob &U = uj.j[uj.njobs];
             U.val = base; U.stride = stride; U.ncols = 1;
-            U.defer = defer; U.nrm64 = se->nrm64; U.nrm32 = se->nrm32; U.q32 = (const float *)it->xyz32; U.row0 = res->begin;
+            U.defer = defer; U.nrm64 = se->nrm64; U.nrm32 = se->nrm32; U.q32 = it->xyz32r; U.row0 = res->begin;
             U.c[0] = col; U.c[1] = col;
             U.ns = ns; U.nunits = s.nunits;
             U.tail_first = s.t0 - res->begin; U.tail_n = s.tail_n;

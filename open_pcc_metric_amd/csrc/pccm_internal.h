@@ -28,6 +28,9 @@ struct Cloud {
     int64_t n_pad = 0;          // multiple of kScanTile
     float4 *xyz32 = nullptr;    // [n_pad/4][3] quads: x0..3 | y0..3 | z0..3; padding rows = kPadCoord
     double *xyz64 = nullptr;    // [n][3]
+    float4 *xyz32r = nullptr;   // [n] {x, y, z, 0}: the fp32 coordinates once more, one aligned 16-byte word per ROW (what the reductions
+                                // of matched-record results read next to the record and the normal: three wide loads per row)
+    size_t cap32r = 0;
     double *nrm64 = nullptr;    // [n_nrm][3]
     float4 *nrm32 = nullptr;    // [n_nrm] {nx, ny, nz, -}: the same normals in one aligned 16-byte word each, when nrm_exact32
     bool nrm_exact32 = false;   // every component survives fp64 -> fp32 -> fp64 (file normals usually do; estimated ones do not)
@@ -230,7 +233,7 @@ struct ProfScope {   // records a HIP-event pair around a launch group when prof
 
 // kernel launchers (each returns PCCM_OK or an error) -----------------------------------
 int launch_ingest_points(pccm_ctx *ctx, const void *src, int dtype, int64_t n, int64_t n_pad, float4 *x32,
-                         double *x64, unsigned long long *stats /*[3] device*/);
+                         double *x64, float4 *x32r, unsigned long long *stats /*[3] device*/);
 int launch_ingest_normals(pccm_ctx *ctx, const void *src, int dtype, int64_t n, double *out, float *out32,
                           unsigned long long *stats);
 
@@ -301,7 +304,7 @@ struct UnitJob {                // one per-point array to reduce (k_unit_jobs): 
     int defer;                  // 0: no; 1: normals as 16-byte fp32-exact words (nrm32); 2: as fp64 rows (nrm64); 3: no normals (field 0 only)
     const double *nrm64;
     const float4 *nrm32;
-    const float *q32;           // iterating cloud, fp32 quads layout (Cloud::xyz32)
+    const float4 *q32;          // iterating cloud, one fp32 word per row (Cloud::xyz32r)
     int64_t row0;               // row of the cloud the shard's first record belongs to
     int ncols;
     UnitCol c[2];
@@ -317,7 +320,7 @@ struct UnitJobs {
 };
 int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs);
 // result records -> plain columns (q32 / row0: the iterating cloud's rows, for records of layout 1)
-int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int layout, const float *q32, int64_t row0, int64_t ns, int32_t *idx, double *d2);
+int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int layout, const float4 *q32, int64_t row0, int64_t ns, int32_t *idx, double *d2);
 int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs);
 
 int launch_point_metric(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int metric,

@@ -19,7 +19,7 @@ __device__ __forceinline__ unsigned long long order_key(double v)
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src, int64_t n, int64_t n_pad,
-                                                       float *__restrict__ x32, double *__restrict__ x64,
+                                                       float *__restrict__ x32, double *__restrict__ x64, float4 *__restrict__ x32r,
                                                        unsigned long long *__restrict__ stats)
 {
     __shared__ unsigned long long s_mx[4], s_lo[4][3], s_hi[4][3];
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_ingest_points(const T *__restrict__ src
             qd[0] = f[0];
             qd[4] = f[1];
             qd[8] = f[2];
+            x32r[i] = make_float4(f[0], f[1], f[2], 0.f);
         } else {
             float *qd = x32 + (i >> 2) * 12 + (i & 3);
             qd[0] = qd[4] = qd[8] = kPadCoord;
@@ -121,15 +122,15 @@ __global__ __launch_bounds__(256) void k_ingest_normals(const T *__restrict__ sr
 }
 
 int launch_ingest_points(pccm_ctx *ctx, const void *src, int dtype, int64_t n, int64_t n_pad, float4 *x32,
-                         double *x64, unsigned long long *stats)
+                         double *x64, float4 *x32r, unsigned long long *stats)
 {
     ProfScope ps(ctx, PCCM_K_INGEST);
     const int64_t blocks = (n_pad + 255) / 256;
     dim3 grid((unsigned)(blocks < 256 ? blocks : 256));
     if (dtype == PCCM_F32)
-        hipLaunchKernelGGL((k_ingest_points<float>), grid, dim3(256), 0, ctx->stream, (const float *)src, n, n_pad, (float *)x32, x64, stats);
+        hipLaunchKernelGGL((k_ingest_points<float>), grid, dim3(256), 0, ctx->stream, (const float *)src, n, n_pad, (float *)x32, x64, x32r, stats);
     else
-        hipLaunchKernelGGL((k_ingest_points<double>), grid, dim3(256), 0, ctx->stream, (const double *)src, n, n_pad, (float *)x32, x64, stats);
+        hipLaunchKernelGGL((k_ingest_points<double>), grid, dim3(256), 0, ctx->stream, (const double *)src, n, n_pad, (float *)x32, x64, x32r, stats);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
@@ -245,18 +246,18 @@ struct UnitView {               // the fields of a job the inner loop needs, in 
     int defer;                  // UnitJob::defer
     const double *nrm64;
     const float4 *nrm32;
-    const float *q32;
+    const float4 *q32;
     int64_t row0;
 };
 
 // The two fields of a result record of layout 1 (the matched record {rx, ry, rz, row}, NNOut::layout) for row `row` of the
 // iterating cloud: squared distance -- nanoflann's accumulation order, as every search kernel evaluates it (gdist64, pccm_grid.h)
 // -- and err . normal[row] -- the FMA chain of emit_result / K3; bit for bit what the searches would have stored.
-__device__ __forceinline__ void matched_fields(const float4 rec, const float *__restrict__ q32, int defer, const double *__restrict__ nrm64,
+__device__ __forceinline__ void matched_fields(const float4 rec, const float4 *__restrict__ q32, int defer, const double *__restrict__ nrm64,
                                                const float4 *__restrict__ nrm32, int64_t row, bool want_proj, double &d2, double &proj)
 {
-    const float *q = q32 + (row >> 2) * 12 + (row & 3);
-    const double qx = (double)q[0], qy = (double)q[4], qz = (double)q[8];
+    const float4 q = q32[row];
+    const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
     const double ex = __dsub_rn(qx, (double)rec.x), ey = __dsub_rn(qy, (double)rec.y), ez = __dsub_rn(qz, (double)rec.z);
     d2 = __dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez));
     proj = 0.0;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
         // column values of one record (e: its index in the shard)
         const double *__restrict__ nrm64 = J.nrm64;
         const float4 *__restrict__ nrm32 = J.nrm32;
-        const float *__restrict__ q32 = J.q32;
+        const float4 *__restrict__ q32 = J.q32;
         const int64_t row0 = J.row0;
         auto cols = [&](const double *p, int64_t e, double out[NC]) {
             if (DEFER) {
@@ -652,7 +653,7 @@ int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
 }
 
 // Result records -> plain columns (only when a consumer wants them: colour kernels, getters, pccm_nn_fetch).
-__global__ __launch_bounds__(256) void k_unpack(const double *__restrict__ rec, int stride, int layout, const float *__restrict__ q32, int64_t row0,
+__global__ __launch_bounds__(256) void k_unpack(const double *__restrict__ rec, int stride, int layout, const float4 *__restrict__ q32, int64_t row0,
                                                 int64_t ns, int32_t *__restrict__ idx, double *__restrict__ d2)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256) void k_unpack(const double *__restrict__ rec, 
     d2[i] = r[0];
 }
 
-int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int layout, const float *q32, int64_t row0, int64_t ns, int32_t *idx, double *d2)
+int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int layout, const float4 *q32, int64_t row0, int64_t ns, int32_t *idx, double *d2)
 {
     if (ns <= 0) return PCCM_OK;
     hipLaunchKernelGGL(k_unpack, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, rec, stride, layout, q32, row0, ns, idx, d2);
