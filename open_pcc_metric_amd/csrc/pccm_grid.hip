@@ -813,10 +813,11 @@ int grid_decide(pccm_ctx *ctx, bool *hostile)
     return PCCM_OK;
 }
 
-// ---- ingest-time spatial order (Cloud::sp) --------------------------------------------------------------------
+// ---- spatial order of a resident cloud (Cloud::sp) ---------------------------------------------------------------
 // One counting sort of the cloud along a Z-order curve over its own bounding box (2^b cells per axis, ~4 points per cell):
-// the same three kernels as the grid build, with Morton-numbered cells.  Per cloud, once per pccm_set_cloud -- part of
-// `end_to_end` / `cold_pair`, not of a step (whose build re-sorts this array into the pair's grid every time).
+// the same three kernels as the grid build, with Morton-numbered cells.  Per cloud, once, by the first pccm_drop_caches behind
+// a search (the caller is about to rebuild the search structures of resident clouds) -- never part of a step, whose build
+// re-sorts this array into the pair's grid every time, and never paid by a pair that is searched once.
 // PCCM_SPATIAL=0 switches it off (A/B runs: the build then reads the rows in the caller's order, as in round 2).
 int spatial_order(pccm_ctx *ctx, Cloud &c)
 {

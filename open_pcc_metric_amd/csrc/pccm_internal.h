@@ -40,12 +40,14 @@ struct Cloud {
     // allocations outlive their content (n / n_nrm / n_rgb say what is there): a context that serves one pair after
     // the other -- the engine pool of _native.py -- does not pay hipFree + hipMalloc per cloud
     // the same points in a spatially coherent order (fp32-exact clouds): Rec32 {x, y, z, original row} sorted along a Z-order
-    // curve over the cloud's own bounding box, made once at ingest (pccm_set_cloud).  The per-step grid build reads it instead
+    // curve over the cloud's own bounding box, made once per cloud -- by the first pccm_drop_caches that follows a search, i.e. when
+    // the caller shows that the resident clouds will be searched again (a one-shot pair never pays for it).  The per-step grid build reads it instead
     // of xyz32: rows that are neighbours in memory are neighbours in space, so the counting sort's scattered stores fall into a
     // few bins per tile and merge into whole lines (WRITE_SIZE 2x -> ~1x the records).  Results never depend on it.
     void *sp = nullptr;
     size_t cap_sp = 0;
     bool sp_valid = false;
+    bool sp_tried = false;      // pccm_drop_caches has already made (or found no use for) the spatial order of this cloud
     size_t cap32 = 0, cap64 = 0, cap_nrm = 0, cap_nrm32 = 0, cap_rgb = 0;
     bool exact32 = true;        // every coordinate survives the fp64 -> fp32 -> fp64 round trip
     bool all_int = false;       // ... and is an integer (voxelised content: exact ties are the rule)
