@@ -89,6 +89,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
     if (ABL & 32) return;                                              // timing only: the empty launch
     const int NT = (int)blockDim.x;
     unsigned long long t_last = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_start = t_last;
     unsigned long long t_sum[6] = {0, 0, 0, 0, 0, 0};
     constexpr int kNRow = BY * BZ;                   // query rows of a brick
     constexpr int kNRun = (BY + 2) * (BZ + 2);       // staged x-runs
@@ -458,9 +459,13 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         }
     }
     if (STAMP && lane == 0) {
+        // one slot per wave (same-address atomics from 33 000 waves serialise and keep finished waves in their slots: round 2's
+        // flush made the stamped kernel several times slower than the one it was meant to describe)
+        unsigned long long *slot = bp.stamps + ((size_t)blockIdx.x * (NT >> 6) + w) * 8;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&bp.stamps[k], t_sum[k]);
-        atomicAdd(&bp.stamps[7], 1ull);                                // waves
+        for (int k = 0; k < 6; ++k) slot[k] = t_sum[k];
+        slot[6] = t_start;
+        slot[7] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -544,18 +549,37 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     if (stamp && !self && !ctx->capturing) {
         // diagnostic build: phase shares of the wave cycles, printed per launch (never part of a timed or captured run)
         static unsigned long long *dev = nullptr;
-        if (!dev && hipMalloc((void **)&dev, 8 * sizeof(unsigned long long)) != hipSuccess) dev = nullptr;
+        static size_t dev_slots = 0;
+        const size_t slots = (size_t)bp.total * (size_t)(nt >> 6);
+        if (slots > dev_slots) {
+            if (dev) (void)hipFree(dev);
+            dev = nullptr;
+            if (hipMalloc((void **)&dev, slots * 8 * sizeof(unsigned long long)) == hipSuccess) dev_slots = slots;
+            else dev_slots = 0;
+        }
         if (dev) {
-            (void)hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), ctx->stream);
+            (void)hipMemsetAsync(dev, 0, slots * 8 * sizeof(unsigned long long), ctx->stream);
             bp.stamps = dev;
             hipLaunchKernelGGL((k_brick_query<false, BY, BZ, true>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-            unsigned long long h[8];
-            (void)hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+            std::vector<unsigned long long> h(slots * 8);
+            (void)hipMemcpyAsync(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
             (void)hipStreamSynchronize(ctx->stream);
-            const double w = h[7] ? (double)h[7] : 1.0;
-            fprintf(stderr, "[pccm] brick stamps (cycles per wave, %llu waves, nt %d, cap %d): bounds+barrier %.0f | staging %.0f | barrier %.0f | "
-                            "first query: scan %.0f + epilogue %.0f | leftovers %.0f\n",
-                    h[7], nt, bp.cap, h[0] / w, h[1] / w, h[2] / w, h[5] / w, (double)(h[3]) / w, h[4] / w);
+            double sum[6] = {0, 0, 0, 0, 0, 0}, life = 0.0;
+            unsigned long long first = ~0ull, last = 0ull;
+            size_t waves = 0;
+            for (size_t i = 0; i < slots; ++i) {
+                const unsigned long long *r = &h[i * 8];
+                if (r[7] == 0) continue;                   // a wave of an empty brick
+                ++waves;
+                for (int k = 0; k < 6; ++k) sum[k] += (double)r[k];
+                life += (double)(r[7] - r[6]);
+                first = r[6] < first ? r[6] : first;
+                last = r[7] > last ? r[7] : last;
+            }
+            const double w = waves ? (double)waves : 1.0;
+            fprintf(stderr, "[pccm] brick stamps (s_memtime ticks per wave, %zu waves, nt %d, cap %d): lifetime %.0f, first start -> last end %.0f | "
+                            "bounds+barrier %.0f | staging %.0f | barrier %.0f | scan %.0f | epilogue %.0f | leftovers %.0f\n",
+                    waves, nt, bp.cap, life / w, (double)(last - first), sum[0] / w, sum[1] / w, sum[2] / w, sum[5] / w, sum[3] / w, sum[4] / w);
             return;
         }
     }

@@ -28,6 +28,20 @@ def main():
             for key, val in want.items():
                 if not (got[key] == val):
                     raise AssertionError(f"{key}: HIP {got[key]!r} != oracle {val!r} (use_graph={use_graph})")
+    # a voxelised pair (integer coordinates, exact ties, unequal sizes): the lattice kernel or whatever PCCM_LATTICE=0 puts in its place
+    rng = np.random.default_rng(21)
+    v = rng.standard_normal((120_000, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    va = np.unique(np.round(200 + 150 * v), axis=0).astype(np.float32)
+    vb = np.unique(np.round(va + rng.normal(0, 0.6, va.shape)), axis=0).astype(np.float32)[: len(va) - 77]
+    vwant = orc.OraclePair(va, vb, None, None, method="kdtree").report(hausdorff=True, point_to_plane_=False, peak=300.0)
+    pair = CloudPair(PointCloud(va), PointCloud(vb), extent=[300.0, 300.0, 300.0], device=0)
+    for _ in range(2):                                  # a first search, then a rebuild (spatial order after pccm_drop_caches)
+        pair.recompute()
+        vgot = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, False))).as_dict()
+        for key, val in vwant.items():
+            if not (vgot[key] == val):
+                raise AssertionError(f"voxelised pair, {key}: HIP {vgot[key]!r} != oracle {val!r}")
     print("ab path ok:", " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("PCCM_")))
 
 
