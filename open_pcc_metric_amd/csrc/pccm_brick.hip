@@ -50,7 +50,20 @@ struct BrickParams {
     uint32_t total;         // bricks of all jobs
     int cap;                // staged records that fit (< 65536: LDS positions are kept as uint16)
     unsigned long long *stamps;   // diagnostic build only (PCCM_BRICK_STAMP=1): per-phase wave-cycle sums, else null
+    // the ring-1 stop rule in fp32 (face32): per axis the cell edge and the two face origins, org - h + slack and org + 2 h - slack,
+    // where slack = GridGeom::slack + the worst absolute error of the fp32 evaluation (see launch_brick_query)
+    float h32[3], face_lo[3], face_hi[3];
 };
+
+// Distance from the query coordinate q (cell c of its axis) to the nearer face of the ring-1 cube that has cells behind it --
+// face_bound() of pccm_grid.h in fp32, never larger than it: the faces lie at org + (c - 1) h and org + (c + 2) h
+__device__ __forceinline__ float face32(float q, int c, int dim, float h, float flo, float fhi)
+{
+    const float cf = (float)c;
+    const float lo = q - __builtin_fmaf(cf, h, flo), hi = __builtin_fmaf(cf, h, fhi) - q;
+    const float a = c >= 2 ? lo : INFINITY, b = c <= dim - 3 ? hi : INFINITY;
+    return a < b ? a : b;
+}
 
 // In-kernel stamps (cdna_hip_programming.md section 7): a SEPARATE instantiation of the kernel, selected by
 // PCCM_BRICK_STAMP=1, adds each wave's cycles per phase into bp.stamps; the product kernel (STAMP = false) executes none.
@@ -63,11 +76,11 @@ struct BrickParams {
         }                                                                                    \
     } while (0)
 
-__device__ __forceinline__ float vmin(float a, float b)      // both finite here
+// min of two non-negative floats (or +inf) by their bit patterns
+__device__ __forceinline__ float umin_f(float a, float b)
 {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    const uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
+    return __uint_as_float(x < y ? x : y);
 }
 
 // the normal of `row`: one aligned 16-byte word when the cloud's normals are fp32-exact (exact widening), else 24 bytes of fp64
@@ -83,7 +96,8 @@ __device__ __forceinline__ void load_normal(const NNOut &o, int row, double &a, 
 }
 
 // N32: every job's normals (if any are fused) are the fp32-exact 16-byte words of nrm32
-template <bool SELF, int BY, int BZ, bool STAMP, int ABL, bool N32>   // ABL: timing-only ablations (PCCM_BRICK_ABLATE), wrong results
+// PL: floats per LDS plane (compile-time: the scan reaches the y and z planes through the DS instructions' immediate offsets)
+template <bool SELF, int BY, int BZ, bool STAMP, int ABL, bool N32, int PL>   // ABL: timing-only ablations (PCCM_BRICK_ABLATE), wrong results
 __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom &g, const BrickParams &bp, const uint32_t vblock)
 {
     if (ABL & 32) return;                                              // timing only: the empty launch
@@ -94,12 +108,16 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
     constexpr int kNRow = BY * BZ;                   // query rows of a brick
     constexpr int kNRun = (BY + 2) * (BZ + 2);       // staged x-runs
     static_assert(kNRun <= 64 && kNRow <= 64, "one wave scans the run / row lengths");
-    // staged records, two per 32-byte slot, component-interleaved: {x0, x1, y0, y1, z0, z1, row0, row1} -- the scan
-    // reads a slot with two ds_read_b128 and has its packed-fp32 operands (x0 x1), (y0 y1), (z0 z1) in place
-    extern __shared__ float4 s_rec[];                // [cap + 2] records = cap / 2 + 1 slots
+    // staged records as four planes x[PL], y[PL], z[PL], row[PL]: the scan reads a pair of candidates with three ds_read_b64
+    // (2 LDS cycles each, 64 banks: 32 consecutive pairs are conflict-free) and has its packed-fp32 operands (x0 x1), (y0 y1),
+    // (z0 z1) in place; rows are read for the winner only.  (Round 2's {x0 x1 y0 y1 | z0 z1 row0 row1} slots took two
+    // ds_read_b128 = 8 cycles, each on half of the banks: 37 % of the kernel's LDS cycles were bank conflicts.)
+    extern __shared__ __attribute__((aligned(16))) float s_pl[];     // 4 x PL floats
+    static_assert(8 * PL * 4 / 2 < 65536 && 12 * PL < 65536, "plane offsets are 16-bit immediates");
     __shared__ uint16_t s_lcs[kNRun * kLcsPitch];
     __shared__ uint32_t s_g0[kNRun], s_len[kNRun], s_base[kNRun + 1], s_qg0[kNRow], s_qoff[kNRow + 1];
-    float *const s_f = reinterpret_cast<float *>(s_rec);
+    float *const s_x = s_pl, *const s_y = s_pl + PL, *const s_z = s_pl + 2 * PL, *const s_r = s_pl + 3 * PL;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)s_x;   // < 8 KB of tables in front, 16-byte aligned; lds0 + 4 PL < 65536: addresses fit uint16
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform by construction: everything derived from it is scalar
     // XCD-aware order: workgroups b, b+8, ... share an XCD; give every XCD one contiguous eighth of the brick list
@@ -286,20 +304,18 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
                 const uint32_t plen = (rl[u] + 1u) & ~1u;
                 if ((uint32_t)lane < plen) {
                     const uint32_t f = rb[u] + (uint32_t)lane;
-                    float *d = s_f + (f >> 1) * 8 + (f & 1u);
-                    d[0] = rec[u].x;
-                    d[2] = rec[u].y;
-                    d[4] = rec[u].z;
-                    d[6] = rec[u].w;
+                    s_x[f] = rec[u].x;
+                    s_y[f] = rec[u].y;
+                    s_z[f] = rec[u].z;
+                    s_r[f] = rec[u].w;
                 }
             }
             if (xp < ((xl + 1u) & ~1u)) {
                 const uint32_t f = xb + xp;
-                float *d = s_f + (f >> 1) * 8 + (f & 1u);
-                d[0] = rex.x;
-                d[2] = rex.y;
-                d[4] = rex.z;
-                d[6] = rex.w;
+                s_x[f] = rex.x;
+                s_y[f] = rex.y;
+                s_z[f] = rex.z;
+                s_r[f] = rex.w;
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -309,20 +325,20 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
                     float4 t = make_float4(kFar, kFar, kFar, __int_as_float(-1));
                     if (!(ABL & 2) && p < rl[u]) t = *reinterpret_cast<const float4 *>(&srecs[rg[u] + p]);
                     const uint32_t f = rb[u] + p;
-                    float *d = s_f + (f >> 1) * 8 + (f & 1u);
-                    d[0] = t.x;
-                    d[2] = t.y;
-                    d[4] = t.z;
-                    d[6] = t.w;
+                    s_x[f] = t.x;
+                    s_y[f] = t.y;
+                    s_z[f] = t.z;
+                    s_r[f] = t.w;
                 }
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int r = r0 + u * nw;
                 if (r < kNRun) {
-                    const uint32_t base = rb[u], rebase = base - rg[u];
-                    if (lane <= ncs) s_lcs[r * kLcsPitch + lane] = (uint16_t)(in[u] ? v[u][0] + rebase : base);
-                    if (lane + 64 <= ncs) s_lcs[r * kLcsPitch + lane + 64] = (uint16_t)(in[u] ? v[u][1] + rebase : base);
+                    // (as LDS byte addresses of the x plane: the scan starts at one and stops at the other without arithmetic)
+                    const uint32_t base = lds0 + 4u * rb[u], rebase = base - 4u * rg[u];
+                    if (lane <= ncs) s_lcs[r * kLcsPitch + lane] = (uint16_t)(in[u] ? 4u * v[u][0] + rebase : base);
+                    if (lane + 64 <= ncs) s_lcs[r * kLcsPitch + lane + 64] = (uint16_t)(in[u] ? 4u * v[u][1] + rebase : base);
                 }
             }
         }
@@ -351,49 +367,50 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         float best = kBigF, second = kBigF;
         uint32_t bestpos = 0xffffffffu;
         const v2f qxx = {q.x, q.x}, qyy = {q.y, q.y}, qzz = {q.z, q.z};
-        const uint32_t lds0 = (uint32_t)(uintptr_t)s_rec;
 #pragma unroll
         for (int dz = 0; dz < 3; ++dz) {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                // (reading all eighteen run bounds up front, in one LDS round trip, costs nine registers the kernel does
-                // not have below 64 and measured no gain)
                 const int run = (lz + dz) * (BY + 2) + (ly + dy);
-                const uint32_t fs = s_lcs[run * kLcsPitch + ja], fe = s_lcs[run * kLcsPitch + jb2];
-                // whole slots [fs / 2, ceil(fe / 2)): a slot may bring one record of the neighbouring cell of the same run
-                // (or the run's pad) along -- a real point of the searched cloud farther away than the face the stop rule
-                // tests, so it can only lose; no per-candidate range test is needed
-                // (the loop runs on LDS byte addresses: the position of the best candidate is kept as its address)
-                for (uint32_t a = lds0 + 32u * (fs >> 1), ae = (ABL & 1) ? a + (fs < fe ? 32u : 0u) : lds0 + 32u * ((fe + 1u) >> 1); a < ae; a += 32u) {
-                    // two ds_read_b128 (4 LDS cycles each).  Left to itself hipcc drops the unused row words and issues
-                    // ds_read_b96, which the LDS serves at 8 cycles per wave (MI355X_MICROARCH.md, LDS table)
-                    float4 ca, cb;                                     // (x0 x1 y0 y1), (z0 z1 row0 row1)
-                    // (ABL & 64, timing only: every lane reads the wave's first address -- a broadcast, no bank conflicts)
-                    const uint32_t ar = (ABL & 64) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a) : a;
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(ca), "=&v"(cb)
-                                 : "v"(ar)
-                                 : "memory");
-                    // both candidates of the slot at once: v_pk_add / v_pk_mul / v_pk_fma_f32
-                    const v2f dx = qxx - v2f{ca.x, ca.y}, dy = qyy - v2f{ca.z, ca.w}, dz = qzz - v2f{cb.x, cb.y};
+                const uint32_t fsb = s_lcs[run * kLcsPitch + ja], feb = s_lcs[run * kLcsPitch + jb2];
+                // whole pairs from the one that holds the window's first record up to its end: a pair may bring one record of
+                // the neighbouring cell of the same run (or the run's pad) along -- a real point of the searched cloud outside
+                // the ring-1 cube: if it wins, the stop rule below rejects it; no per-candidate range test is needed
+                // (the loop runs on LDS byte addresses of the x plane: the position of the best candidate is kept as its address)
+                for (uint32_t a = fsb & ~7u, ae = (ABL & 1) ? (fsb < feb ? a + 8u : a) : feb; a < ae; a += 8u) {
+                    // three ds_read_b64 off one address register (left to itself hipcc fuses two of them into a
+                    // ds_read2st64_b64, which the LDS serves at 8 cycles per wave: MI355X_MICROARCH.md, LDS table)
+                    v2f px, py, pz, pr;
+                    if (SELF)
+                        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b64 %2, %4 offset:%6\n\t"
+                                     "ds_read_b64 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(px), "=&v"(py), "=&v"(pz), "=&v"(pr)
+                                     : "v"(a), "n"(4 * PL), "n"(8 * PL), "n"(12 * PL)
+                                     : "memory");
+                    else
+                        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%4\n\tds_read_b64 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(px), "=&v"(py), "=&v"(pz)
+                                     : "v"(a), "n"(4 * PL), "n"(8 * PL)
+                                     : "memory");
+                    // both candidates of the pair at once: v_pk_add / v_pk_mul / v_pk_fma_f32
+                    const v2f dx = qxx - px, dy = qyy - py, dz = qzz - pz;
                     v2f dd = dx * dx;
                     dd = __builtin_elementwise_fma(dy, dy, dd);
                     dd = __builtin_elementwise_fma(dz, dz, dd);
                     float d0 = dd.x, d1 = dd.y;
                     if (SELF) {
-                        d0 = (__float_as_int(cb.z) == qrow) ? kBigF : d0;
-                        d1 = (__float_as_int(cb.w) == qrow) ? kBigF : d1;
+                        d0 = (__float_as_int(pr.x) == qrow) ? kBigF : d0;
+                        d1 = (__float_as_int(pr.y) == qrow) ? kBigF : d1;
                     }
-                    // best / second over both candidates; the winner is remembered per SLOT (which of its two records it
-                    // was is found again after the scan: the same arithmetic gives the same bits) -- 6 VALU where tracking
-                    // the record itself took 9
-                    // (v_min_f32 by hand: for fminf hipcc canonicalises the loop-carried operand first, one more VALU)
-                    const float bprev = best;
-                    second = __builtin_amdgcn_fmed3f(best, second, d0);
-                    best = vmin(best, d0);
-                    second = __builtin_amdgcn_fmed3f(best, second, d1);
-                    best = vmin(best, d1);
-                    bestpos = best < bprev ? a : bestpos;
+                    // The nearer of the two enters (best, second best, address of the best pair); the farther one is checked
+                    // once, after the scan, for the winning pair only: a pair's farther record can be second best without its
+                    // nearer one being best or second best only as the winner's own partner.  5 VALU per pair (tracking both
+                    // records: 7).  Squared distances are non-negative (or +inf): their order is the order of their bit
+                    // patterns, and v_min_u32 needs no canonicalisation of the loop-carried operand (fminf does)
+                    const float lo = umin_f(d0, d1);
+                    bestpos = __float_as_uint(lo) < __float_as_uint(best) ? a : bestpos;
+                    second = __builtin_amdgcn_fmed3f(best, second, lo);
+                    best = umin_f(best, lo);
                 }
             }
         }
@@ -407,27 +424,39 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
             if (best < 0.0f) store_result(out, qrow, 0.0, 0.0, 0);     // never true: keeps the scan alive
             settled = true;
         } else if (bestpos != 0xffffffffu && best < 1.0e30f && second > thr) {          // (a pad record is no neighbour)
-            // the winning slot's two records again: which one has d32 == best?  (both: then second == best and the
-            // certificate above has already failed)
-            const float *c = s_f + ((bestpos - lds0) >> 2);         // byte address of the slot
+            // the winning pair's two records again: which one has d32 == best (the same arithmetic gives the same bits), and
+            // is its partner out of the way?  (both at d32 == best: an exact tie, left to the tail kernels like every near tie)
+            uint32_t f = (bestpos - lds0) >> 2;                     // the pair's first record
+            float partner;
             {
-                const float4 ca = *reinterpret_cast<const float4 *>(c), cb = *reinterpret_cast<const float4 *>(c + 4);
-                const v2f dx = qxx - v2f{ca.x, ca.y}, dy = qyy - v2f{ca.z, ca.w}, dz = qzz - v2f{cb.x, cb.y};
+                const v2f px = *reinterpret_cast<const v2f *>(s_x + f), py = *reinterpret_cast<const v2f *>(s_y + f),
+                          pz = *reinterpret_cast<const v2f *>(s_z + f);
+                const v2f dx = qxx - px, dy = qyy - py, dz = qzz - pz;
                 v2f dd = dx * dx;
                 dd = __builtin_elementwise_fma(dy, dy, dd);
                 dd = __builtin_elementwise_fma(dz, dz, dd);
-                float d0 = dd.x;
-                if (SELF) d0 = (__float_as_int(cb.z) == qrow) ? kBigF : d0;
+                float d0 = dd.x, d1 = dd.y;
+                if (SELF) {
+                    d0 = (__float_as_int(s_r[f]) == qrow) ? kBigF : d0;
+                    d1 = (__float_as_int(s_r[f + 1]) == qrow) ? kBigF : d1;
+                }
                 const bool first = d0 == best;
-                c += first ? 0 : 1;
+                partner = first ? d1 : d0;
+                f += first ? 0u : 1u;
             }
-            const double rx = (double)c[0], ry = (double)c[2], rz = (double)c[4];
-            const int wrow = __float_as_int(c[6]);
-            const double d64 = gdist64(qx, qy, qz, rx, ry, rz);
-            settled = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, 1), d64);
+            // the ring-1 stop rule, in fp32 and never more permissive than settled_by(face_bound(.., 1), d64): the true squared
+            // distance is below best (1 + 2^-19) (the certification bound above), L is a lower bound of the face distance
+            float L = face32(q.x, cx, dimx, bp.h32[0], bp.face_lo[0], bp.face_hi[0]);
+            L = fminf(L, face32(q.y, cy, dimy, bp.h32[1], bp.face_lo[1], bp.face_hi[1]));
+            L = fminf(L, face32(q.z, cz, dimz, bp.h32[2], bp.face_lo[2], bp.face_hi[2]));
+            settled = partner > thr && L > 0.0f && best * 1.00001f < L * L * 0.99999f;
+            const float wx = s_x[f], wy = s_y[f], wz = s_z[f];
+            const int wrow = __float_as_int(s_r[f]);
             if (settled && defer) {
-                store_result_rec(out, qrow, c[0], c[2], c[4], wrow);        // the matched record as it lies in LDS: one 16-byte store
+                store_result_rec(out, qrow, wx, wy, wz, wrow);              // the matched record as it lies in LDS: one 16-byte store
             } else if (settled) {
+                const double rx = (double)wx, ry = (double)wy, rz = (double)wz;
+                const double d64 = gdist64(qx, qy, qz, rx, ry, rz);
                 double p = 0.0;
                 if (fuse) {
                     double e0 = N32 ? (double)nraw.x : n0, e1 = N32 ? (double)nraw.y : n1, e2 = N32 ? (double)nraw.z : n2;
@@ -476,16 +505,16 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
 // kernel lives on occupancy (two workgroups per CU: 148 us, three: 112 us, four: 104 us at 1M points).  With 81-96 SGPRs
 // the hardware admits one wave per SIMD less than the compiler's occupancy figure says (MI355X_MICROARCH.md, "Residency
 // and cooperative launch").  PCCM_BRICK_V64=0 runs the build without the cap (72 VGPRs, 93 SGPRs) for A/B.
-template <bool SELF, int BY, int BZ, bool STAMP = false, int ABL = 0, bool N32 = true>
+template <bool SELF, int BY, int BZ, int PL, bool STAMP = false, int ABL = 0, bool N32 = true>
 __global__ __launch_bounds__(1024, 8) void k_brick_query(QueryJobs jobs, GridGeom g, BrickParams bp)
 {
-    brick_body<SELF, BY, BZ, STAMP, ABL, N32>(jobs, g, bp, blockIdx.x);
+    brick_body<SELF, BY, BZ, STAMP, ABL, N32, PL>(jobs, g, bp, blockIdx.x);
 }
 
-template <int BY, int BZ>
+template <int BY, int BZ, int PL>
 __global__ __launch_bounds__(1024) void k_brick_query_free(QueryJobs jobs, GridGeom g, BrickParams bp)
 {
-    brick_body<false, BY, BZ, false, 0, false>(jobs, g, bp, blockIdx.x);
+    brick_body<false, BY, BZ, false, 0, false, PL>(jobs, g, bp, blockIdx.x);
 }
 
 // brick shape: PCCM_BRICK="BY,BZ[,NT]" picks one of the compiled shapes and optionally forces the workgroup size (A/B runs)
@@ -508,39 +537,29 @@ static BrickShape brick_shape()
     return s;
 }
 
-template <int BY, int BZ>
-static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density_s,
-                         double density_q, int force_nt)
+// plane sizes the kernels are compiled for: the small one holds the bricks of whole clouds at ~1.4 points per cell with four
+// workgroups per CU (4 x 2176 floats + 3.6 KB of tables = 38.4 KB), the large one is the 64 KB workgroup limit
+constexpr int kPlaneTight = 1728, kPlaneSmall = 2176, kPlaneLarge = 3584;
+
+template <int BY, int BZ, int PL>
+static void launch_plane(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density_q, int force_nt)
 {
-    bp.nby = (g.dim[1] + BY - 1) / BY;
-    bp.nbz = (g.dim[2] + BZ - 1) / BZ;
-    bp.per_job = (int64_t)bp.nbx * bp.nby * bp.nbz;
-    // LDS budget: the expected number of staged records (runs x cells x points per cell) plus a quarter -- occupancy
-    // is set by it.  Bricks that hold more (clumped data) hand their queries to the general kernels.
-    const double expect = (double)((BY + 2) * (BZ + 2)) * (bp.bx + 2) * density_s;
-    int cap = (int)(1.25 * expect) + 64;
-    static const int cap_env = [] { const char *e = getenv("PCCM_BRICK_CAP"); return e ? atoi(e) : 0; }();
-    if (cap_env > 0) cap = cap_env;
-    if (cap < 256) cap = 256;
-    // static + dynamic LDS of one workgroup stay under 64 KB: the statics are s_lcs (kNRun x kLcsPitch uint16) and five
-    // run / row tables -- 3.6 KB for the 4 x 2 shape, 5.5 KB for 4 x 4
     constexpr int kStatic = (BY + 2) * (BZ + 2) * (kLcsPitch * 2 + 12) + (BY * BZ) * 8 + 64;
-    const int cap_max = (64 * 1024 - kStatic) / (int)sizeof(float4) - 2;
-    if (cap > cap_max) cap = cap_max;
-    bp.cap = cap;
+    static_assert(4 * PL * (int)sizeof(float) + kStatic <= 64 * 1024, "static + dynamic LDS of one workgroup stay under 64 KB");
     // workgroup size: the queries a brick is expected to hold plus 2.5 sigma (Poisson), in whole waves -- but never
     // so large that the workgroups the LDS admits per CU exceed the CU's 32 wave slots (occupancy is what hides the
     // kernel's memory round trips: a few leftover queries per brick cost less than a workgroup per CU)
     const double eq = (double)(BY * BZ) * bp.bx * density_q;
     int nt = ((int)(eq + 2.5 * sqrt(eq)) + 63) / 64 * 64;
-    const size_t lds_wg = (size_t)(bp.cap + 2) * sizeof(float4) + (size_t)((BY + 2) * (BZ + 2)) * (kLcsPitch * 2 + 16) + 256;
+    const size_t lds = (size_t)4 * PL * sizeof(float);
+    const size_t lds_wg = lds + (size_t)((BY + 2) * (BZ + 2)) * (kLcsPitch * 2 + 16) + 256;
     const int wgs_per_cu = (int)((size_t)160 * 1024 / lds_wg) > 0 ? (int)((size_t)160 * 1024 / lds_wg) : 1;
-    const int nt_cap = 64 * (32 / (wgs_per_cu > 16 ? 16 : wgs_per_cu));
+    static const int wave_slots = [] { const char *e = getenv("PCCM_BRICK_SLOTS"); return e ? atoi(e) : 32; }();
+    const int nt_cap = 64 * (wave_slots / (wgs_per_cu > 16 ? 16 : wgs_per_cu));
     if (nt > nt_cap) nt = nt_cap;
     if (force_nt > 0) nt = force_nt / 64 * 64;
     if (nt < 128) nt = 128;                             // waves 0 and 1 do the bookkeeping of step 1
     if (nt > 1024) nt = 1024;
-    const size_t lds = (size_t)(bp.cap + 2) * sizeof(float4);
     bp.total = (uint32_t)(bp.per_job * jobs.njobs);
     dim3 grid(bp.total);
     bp.stamps = nullptr;
@@ -560,7 +579,7 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
         if (dev) {
             (void)hipMemsetAsync(dev, 0, slots * 8 * sizeof(unsigned long long), ctx->stream);
             bp.stamps = dev;
-            hipLaunchKernelGGL((k_brick_query<false, BY, BZ, true>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+            hipLaunchKernelGGL((k_brick_query<false, BY, BZ, PL, true>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
             std::vector<unsigned long long> h(slots * 8);
             (void)hipMemcpyAsync(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
             (void)hipStreamSynchronize(ctx->stream);
@@ -585,29 +604,55 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     }
     static const int ablate = [] { const char *e = getenv("PCCM_BRICK_ABLATE"); return e ? atoi(e) : 0; }();
     if (ablate && !self && BY == 4 && BZ == 2) {        // timing-only builds: results are wrong by construction
-        if (ablate == 1) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 1>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-        else if (ablate == 2) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 2>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-        else if (ablate == 4) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 4>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-        else if (ablate == 8) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 8>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-        else if (ablate == 7) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 7>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-        else if (ablate == 16) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 16>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-        else if (ablate == 32) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 32>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-        else if (ablate == 68) hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 68>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-        else hipLaunchKernelGGL((k_brick_query<false, 4, 2, false, 15>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        if (ablate == 1) hipLaunchKernelGGL((k_brick_query<false, 4, 2, PL, false, 1>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 2) hipLaunchKernelGGL((k_brick_query<false, 4, 2, PL, false, 2>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 4) hipLaunchKernelGGL((k_brick_query<false, 4, 2, PL, false, 4>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 8) hipLaunchKernelGGL((k_brick_query<false, 4, 2, PL, false, 8>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 16) hipLaunchKernelGGL((k_brick_query<false, 4, 2, PL, false, 16>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else if (ablate == 32) hipLaunchKernelGGL((k_brick_query<false, 4, 2, PL, false, 32>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        else hipLaunchKernelGGL((k_brick_query<false, 4, 2, PL, false, 15>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         return;
     }
 #endif
     static const bool v_free = [] { const char *e = getenv("PCCM_BRICK_V64"); return e && e[0] == '0'; }();
     if (v_free && !self) {     // A/B: no register cap
-        hipLaunchKernelGGL((k_brick_query_free<BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+        hipLaunchKernelGGL((k_brick_query_free<BY, BZ, PL>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         return;
     }
     // fp32-exact normals (file normals) or none fused: the kernel that carries the 16-byte word; fp64 rows (estimated normals) else
     bool n32 = true;
     for (int k = 0; k < jobs.njobs; ++k) n32 = n32 && (jobs.j[k].out.nrm == nullptr || jobs.j[k].out.nrm32 != nullptr);
-    if (self) hipLaunchKernelGGL((k_brick_query<true, BY, BZ>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);     // (no normals in a self search)
-    else if (n32) hipLaunchKernelGGL((k_brick_query<false, BY, BZ, false, 0, true>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
-    else hipLaunchKernelGGL((k_brick_query<false, BY, BZ, false, 0, false>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+    if (self) hipLaunchKernelGGL((k_brick_query<true, BY, BZ, PL>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);     // (no normals in a self search)
+    else if (n32) hipLaunchKernelGGL((k_brick_query<false, BY, BZ, PL, false, 0, true>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+    else hipLaunchKernelGGL((k_brick_query<false, BY, BZ, PL, false, 0, false>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
+}
+
+template <int BY, int BZ>
+static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density_s,
+                         double density_q, int force_nt)
+{
+    bp.nby = (g.dim[1] + BY - 1) / BY;
+    bp.nbz = (g.dim[2] + BZ - 1) / BZ;
+    bp.per_job = (int64_t)bp.nbx * bp.nby * bp.nbz;
+    // LDS budget: the expected number of staged records (runs x cells x points per cell) plus a quarter -- occupancy
+    // is set by it.  Bricks that hold more (clumped data) hand their queries to the general kernels.
+    const double expect = (double)((BY + 2) * (BZ + 2)) * (bp.bx + 2) * density_s;
+    int cap = (int)(1.25 * expect) + 64;
+    static const int cap_env = [] { const char *e = getenv("PCCM_BRICK_CAP"); return e ? atoi(e) : 0; }();
+    if (cap_env > 0) cap = cap_env;
+    if (cap < 256) cap = 256;
+    // the kernels are compiled for two plane sizes; the budget is the whole plane (it is allocated either way)
+    static const int pl_env = [] { const char *e = getenv("PCCM_BRICK_PL"); return e ? atoi(e) : 0; }();
+    if (pl_env == kPlaneTight) {
+        bp.cap = kPlaneTight - 2;
+        launch_plane<BY, BZ, kPlaneTight>(ctx, jobs, g, self, bp, density_q, force_nt);
+    } else if (cap + 2 <= kPlaneSmall) {
+        bp.cap = kPlaneSmall - 2;
+        launch_plane<BY, BZ, kPlaneSmall>(ctx, jobs, g, self, bp, density_q, force_nt);
+    } else {
+        bp.cap = kPlaneLarge - 2;
+        launch_plane<BY, BZ, kPlaneLarge>(ctx, jobs, g, self, bp, density_q, force_nt);
+    }
 }
 
 int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self)
@@ -624,6 +669,19 @@ int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, 
     bp.total = 0;
     bp.cap = 0;
     bp.stamps = nullptr;
+    // The stop rule's faces in fp32.  A face lies at F = org + k h; the kernel forms fmaf((float)c, h32, f32) with f32 the rounded
+    // org - h (or org + 2 h) and subtracts the query coordinate.  Against the exact F - q that is off by at most
+    //   |c| |h32 - h| + |f32 - f| + the fma's rounding + the subtraction's rounding  <=  4 x 2 M 2^-24,
+    // M = the largest coordinate magnitude of the grid's box (+ 2 h).  That error joins GridGeom::slack and is taken off every
+    // face distance, so the fp32 bound never exceeds face_bound()'s.
+    for (int a = 0; a < 3; ++a) {
+        const double top = g.org[a] + (double)g.dim[a] * g.h[a];
+        const double M = fmax(fabs(g.org[a]), fabs(top)) + 2.0 * g.h[a];
+        const double slack = g.slack[a] + 8.0 * M * 0x1.0p-24;
+        bp.h32[a] = (float)g.h[a];
+        bp.face_lo[a] = (float)(g.org[a] - g.h[a] + slack);
+        bp.face_hi[a] = (float)(g.org[a] + 2.0 * g.h[a] - slack);
+    }
     const Grid &gr = ctx->grid;
     const int64_t nmax = gr.n[0] > gr.n[1] ? gr.n[0] : gr.n[1];
     const double density = gr.ncells > 0 ? (double)nmax / (double)gr.ncells : 1.5;      // points per cell of the denser cloud
