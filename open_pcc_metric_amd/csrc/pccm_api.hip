@@ -714,6 +714,7 @@ static int prepare_nn(pccm_ctx *ctx, int dir, int *trivial)
         if (rc2) return rc2;
     }
     res.rec_valid = false;
+    res.no_rows = false;
     res.plain_valid = res.plain_d2_valid = ns <= 0;          // an empty shard has nothing to unpack
     res.fused_mode = -1;
     res.stats[0] = res.stats[1] = res.stats[2] = 0;
@@ -801,7 +802,7 @@ static int ensure_plain(pccm_ctx *ctx, NNResult &res, bool need_idx)
 {
     if (res.plain_valid || (!need_idx && res.plain_d2_valid)) return PCCM_OK;
     if (!res.rec_valid) return fail(PCCM_E_STATE, "no nearest-neighbour result to read");
-    if (need_idx && res.rec_stride != 4 && res.rec_layout != 1) {      // (matched records always carry the row)
+    if (need_idx && ((res.rec_stride != 4 && res.rec_layout != 1) || res.no_rows)) {   // (matched records carry the row, the voxel-brick search's excepted)
         // the search ran without the matched rows (pccm_nn_want_idx off) and now somebody asks for them: run it again
         // for this direction with the rows on -- same results, 32-byte records; the clouds and the grid are resident
         if (ctx->capturing) {
@@ -812,7 +813,7 @@ static int ensure_plain(pccm_ctx *ctx, NNResult &res, bool need_idx)
         int rc = nn_grid(ctx, 1, &dir, /*force_idx=*/1);
         if (rc) return rc;
     }
-    const bool rows = res.rec_stride == 4 || res.rec_layout == 1;
+    const bool rows = (res.rec_stride == 4 || res.rec_layout == 1) && !res.no_rows;
     const int udir = (int)(&res - ctx->nn);
     const Cloud &uit = ctx->cloud[udir == PCCM_DIR_RIGHT ? 1 : 0];
     int rc = launch_unpack(ctx, (const double *)res.rec.p, res.rec_stride, res.rec_layout, uit.xyz32r, res.begin, res.end - res.begin,
@@ -993,7 +994,7 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         if (metric != PCCM_METRIC_D2 && metric != PCCM_METRIC_PROJ) return fail(PCCM_E_ARG, "bad metric %d", metric);
         if (dir == PCCM_DIR_SELF) return fail(PCCM_E_ARG, "point-to-plane is not defined for the self search");
         if ((rc = check_normals(ctx, *it, *se, *res, normal_mode))) return rc;
-        if (res->rec_valid && (res->fused_mode == normal_mode || (res->rec_layout == 1 && normal_mode == PCCM_NORMAL_ROW))) {
+        if (res->rec_valid && !res->no_rows && (res->fused_mode == normal_mode || (res->rec_layout == 1 && normal_mode == PCCM_NORMAL_ROW))) {
             dev = (const double *)res->rec.p + 1;
             stride = res->rec_stride;
             square = metric == PCCM_METRIC_D2 ? 1 : 0;       // metric.py:179: the square of the stored projection
@@ -1132,7 +1133,7 @@ static int prefetch_many(pccm_ctx *ctx, int n, const int *dirs, const int *metri
         if (dirs[k] < 0 || dirs[k] > 2) return fail(PCCM_E_ARG, "bad direction %d", dirs[k]);
         if (metrics[k] == PCCM_METRIC_D1 || dirs[k] == PCCM_DIR_SELF) continue;
         NNResult &res = ctx->nn[dirs[k]];
-        if (!res.valid || !res.rec_valid || res.fused_mode == normal_modes[k] || res.rec_stride == 4 || res.rec_layout == 1) continue;
+        if (!res.valid || !res.rec_valid || ((res.fused_mode == normal_modes[k] || res.rec_stride == 4 || res.rec_layout == 1) && !res.no_rows)) continue;
         if (slot_find(ctx, dirs[k], metrics[k], normal_modes[k], want_units)) continue;
         int rc = ensure_plain(ctx, res, true);
         if (rc) return rc;
@@ -1476,6 +1477,7 @@ static int graph_replay(pccm_ctx *ctx, GraphRec &g)
             ctx->nn[op.dir].fused_mode = op.fused_mode;
             ctx->nn[op.dir].rec_stride = op.rec_stride;
             ctx->nn[op.dir].rec_layout = op.rec_layout;
+            ctx->nn[op.dir].no_rows = op.no_rows;
             ctx->nn[op.dir].plain_d2_valid = op.plain_valid;
         } else if (op.kind == 2) {
             ReduceSlot &s = ctx->slots[op.slot];
@@ -1541,6 +1543,7 @@ int pccm_graph_end(pccm_ctx *ctx, int *graph_id)
             op.fused_mode = ctx->nn[op.dir].fused_mode;
             op.rec_stride = ctx->nn[op.dir].rec_stride;
             op.rec_layout = ctx->nn[op.dir].rec_layout;
+            op.no_rows = ctx->nn[op.dir].no_rows;
         }
     g.epoch = ctx->epoch;
     g.valid = true;

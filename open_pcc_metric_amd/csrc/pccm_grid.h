@@ -202,6 +202,10 @@ struct QueryJob {
     int64_t nq, nchunks;        // nchunks = ceil(nq / 64)
     const uint32_t *cs;         // searched cloud's cell starts (positions in srecs)
     const uint32_t *occ;        // ... and its occupancy bitmap (voxelised pairs), or null
+    const uint32_t *vbricks = nullptr;   // voxel-brick grids (pccm_vox.hip): the searched cloud's bricks, 32 words at the index of
+                                         // a cell's first record ...
+    const uint32_t *vlist = nullptr;     // ... the ITERATING cloud's occupied cells, in cell order ...
+    const uint32_t *vcount = nullptr;    // ... and how many they are
     const void *srecs;          // searched cloud's records
     const double *s64;          // searched cloud's fp64 rows (emit_result_lookup)
     int64_t row_base;           // first row of the shard (outputs are indexed row - row_base)
@@ -238,6 +242,24 @@ __device__ __forceinline__ bool settled_by(double L, double d)
 {
     return (L == INFINITY) || (L > 0.0 && d < L * L * (1.0 - 0x1.0p-30));
 }
+
+// voxel-brick grids (pccm_vox.hip): cells of 8 x 8 x 8 voxels, a 512-bit occupancy brick + a brick of the voxels that hold several
+// points per occupied cell
+struct VoxBuildJob {
+    const uint32_t *cs;     // the cloud's cell starts
+    const void *recs;       // its cell-sorted Rec32 records
+    uint32_t *bricks;       // [records][32]
+    const uint32_t *occ;    // the cloud's occupancy bitmap (one bit per cell, written by the build: BuildJob::occ)
+    uint32_t *list;         // occupied cells in cell order, [<= records]
+    uint32_t *count;        // their number
+};
+struct VoxBuild {
+    VoxBuildJob j[2];
+    int njobs;
+    int64_t ncells;
+};
+int launch_vox_bricks(pccm_ctx *ctx, const VoxBuild &vb, const GridGeom &g);
+int launch_vox_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self);
 
 // per-thread search for voxelised (integer-valued) pairs on Rec32 grids (pccm_lattice.hip)
 int launch_lattice_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self);

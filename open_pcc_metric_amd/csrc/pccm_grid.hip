@@ -489,7 +489,7 @@ static bool use_coop(const pccm_ctx *ctx)
 // One geometry for BOTH clouds (union bounding box, cell edge from the mean point count): a query's
 // cell in the searched cloud's grid is then the cell it was sorted into in its own cloud's grid, which is
 // what lets the cooperative kernel work on runs of consecutive cells.
-static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells, double h_scale)
+static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells, double h_scale, bool vox = false)
 {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     double npts = 0.0;
@@ -510,6 +510,20 @@ static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells, d
             hi[a] = ctx->grid.box_hi[a];
         }
     npts /= (nset > 0 ? nset : 1);
+    if (vox) {
+        // voxel-brick flavour (pccm_vox.hip; vox_feasible() has checked the box): cells of exactly 8 x 8 x 8 voxels from the
+        // integer lower corner of the bounding box -- cell_coord is exact integer arithmetic then
+        ncells = 1;
+        for (int a = 0; a < 3; ++a) {
+            g.org[a] = lo[a];
+            g.h[a] = 8.0;
+            g.inv_h[a] = 0.125;
+            g.dim[a] = (int)floor((hi[a] - lo[a]) * 0.125) + 1;
+            g.slack[a] = (fabs(g.org[a]) + (g.dim[a] + 2) * g.h[a]) * 0x1.0p-48;
+            ncells *= g.dim[a];
+        }
+        return;
+    }
     double ext[3];
     int nz = 0;
     double vol = 1.0;
@@ -869,6 +883,26 @@ static bool lattice_pair(const pccm_ctx *ctx, const GridGeom &g, bool rec32)
            g.h[0] <= 256.0 && g.h[1] <= 256.0 && g.h[2] <= 256.0;
 }
 
+// Voxel-brick flavour of the pair's grid (pccm_vox.hip): both clouds voxelised, whole, and a bounding box that 8-voxel cells
+// cover within the budgets below.  PCCM_VOX=0 switches it off (A/B runs: the per-thread lattice search then).
+static bool vox_feasible(const pccm_ctx *ctx)
+{
+    static const bool off = [] { const char *e = getenv("PCCM_VOX"); return e && e[0] == '0'; }();
+    const Cloud &c0 = ctx->cloud[0], &c1 = ctx->cloud[1];
+    static const bool lattice_off = [] { const char *e = getenv("PCCM_LATTICE"); return e && e[0] == '0'; }();
+    if (off || lattice_off || use_coop(ctx) || ctx->grid.boxed || c0.n <= 0 || c1.n <= 0 || !c0.exact32 || !c1.exact32 || !c0.all_int ||
+        !c1.all_int) return false;
+    if (!(c0.maxabs < 4194304.0 && c1.maxabs < 4194304.0)) return false;
+    double cells = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        const double lo = fmin(c0.bb_min[a], c1.bb_min[a]), hi = fmax(c0.bb_max[a], c1.bb_max[a]);
+        const double d = floor((hi - lo) * 0.125) + 1.0;
+        if (!(d <= 2048.0)) return false;
+        cells *= d;
+    }
+    return cells <= (double)(1ll << 24);
+}
+
 // (re)build the combined grid when either cloud changed, the caches were dropped or the record layout asked for
 // differs from the built one (need64: a caller that reads GridRec records, pccm_normals.hip)
 // A shard's rows of the iterating cloud that want the same cell sort as the grid being built: when exactly one cloud is
@@ -882,14 +916,15 @@ struct ShardSort {
 };
 
 static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, uint32_t *zero = nullptr, int nzero = 0, bool *rebuilt = nullptr,
-                       ShardSort *shard = nullptr)
+                       ShardSort *shard = nullptr, bool want_vox = false)
 {
     if (rebuilt) *rebuilt = false;
     Grid &gr = ctx->grid;
     const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
     const bool rec32 = !need64 && pair_rec32(ctx);
+    const bool vox = want_vox && rec32 && !shard && vox_feasible(ctx);
     const bool same = gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p && gr.rec32 == rec32 &&
-                      (!rec32 || gr.lattice == lattice_pair(ctx, geom_of(gr), rec32));
+                      gr.vox == vox && (!rec32 || gr.lattice == lattice_pair(ctx, geom_of(gr), rec32));
     if (same && (gr.built & need_mask) == need_mask) return PCCM_OK;
     if (same) need_mask |= gr.built;                   // keep what is there, add what is missing
     int rc0 = decide_scale(ctx, key);
@@ -897,9 +932,14 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
     ProfScope ps(ctx, PCCM_K_GRID_BUILD);
     GridGeom g;
     int64_t ncells;
-    choose_geometry(ctx, g, ncells, gr.scale);
+    choose_geometry(ctx, g, ncells, gr.scale, vox);
     const int64_t n0 = ctx->cloud[0].n, n1 = ctx->cloud[1].n;
     int rc;
+    if (vox) {
+        if ((rc = ensure(ctx, gr.vbricks, (size_t)(n0 + n1) * 32 * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, gr.vlist, (size_t)(n0 + n1) * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(ctx, gr.vcount, 2 * sizeof(uint32_t)))) return rc;
+    }
     if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;   // either layout fits
     uint32_t *cs = (uint32_t *)gr.cell_start.p;
@@ -935,6 +975,19 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
         shard->done = true;
     }
     if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, ncells, first, rec32, zero, nzero))) return rc;
+    if (vox && jobs.total > 0) {                           // bricks of the clouds just built
+        VoxBuild vb;
+        vb.njobs = 0;
+        vb.ncells = ncells;
+        for (int k = 0; k < 2; ++k) {
+            if (!(need_mask & (1 << k))) continue;
+            const size_t r0 = (size_t)(k ? n0 : 0);
+            vb.j[vb.njobs++] = {cs + (size_t)k * (ncells + 1), (const char *)gr.recs.p + r0 * rsz, (uint32_t *)gr.vbricks.p + r0 * 32,
+                                (const uint32_t *)gr.occ.p + (size_t)k * occ_words, (uint32_t *)gr.vlist.p + r0, (uint32_t *)gr.vcount.p + k};
+        }
+        if (vb.njobs == 1) vb.j[1] = vb.j[0];
+        if (vb.njobs > 0 && (rc = launch_vox_bricks(ctx, vb, g))) return rc;
+    }
     if (rebuilt) *rebuilt = jobs.total > 0;
     for (int a = 0; a < 3; ++a) {
         gr.dim[a] = g.dim[a];
@@ -948,6 +1001,7 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
     gr.key = key;
     gr.rec32 = rec32;
     gr.lattice = lattice;
+    gr.vox = vox;
     gr.built = need_mask;
     return PCCM_OK;
 }
@@ -1112,8 +1166,19 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         }
     }
     if (nsh != 1) ride_dir = -1;
+    // Distances only?  Then a voxelised pair is searched through its voxel bricks (pccm_vox.hip): nobody has asked for the matched
+    // rows (pccm_nn_want_idx off, no repeat of a search for them) and no projection is to be fused (an exact tie decides whose
+    // error vector is projected).  Whole clouds only.
+    bool want_vox = !ctx->want_idx && !force_idx && nsh == 0;
+    for (int d = 0; d < ndirs && want_vox; ++d) {
+        const int dir = dirs[d];
+        const NNResult &res = ctx->nn[dir];
+        if (res.end <= res.begin) continue;
+        const Cloud &it = ctx->cloud[dir == PCCM_DIR_RIGHT ? 1 : 0], &se = ctx->cloud[dir == PCCM_DIR_LEFT ? 1 : 0];
+        if (fused_mode(ctx, dir, it, se) >= 0) want_vox = false;
+    }
     if ((rc = ensure_grid(ctx, false, need, side_by_side ? (uint32_t *)ctx->counters.p + 2 * dlo : nullptr, 2 * ndirs, &rebuilt,
-                          ride_dir >= 0 ? &ride : nullptr))) return rc;
+                          ride_dir >= 0 ? &ride : nullptr, want_vox))) return rc;
     const Grid &gr = ctx->grid;
     const GridGeom g = geom_of(gr);
     const uint32_t *cs_all = (const uint32_t *)gr.cell_start.p;
@@ -1162,6 +1227,11 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         J.nchunks = (nq + 63) / 64;
         J.cs = cs_all + (si ? gr.ncells + 1 : 0);
         J.occ = gr.lattice ? (const uint32_t *)gr.occ.p + (size_t)si * (gr.ncells / 32 + 2) : nullptr;
+        if (gr.vox) {
+            J.vbricks = (const uint32_t *)gr.vbricks.p + (size_t)(si ? gr.n[0] : 0) * 32;
+            J.vlist = (const uint32_t *)gr.vlist.p + (size_t)(ii ? gr.n[0] : 0);
+            J.vcount = (const uint32_t *)gr.vcount.p + ii;
+        }
         J.srecs = recs_all + (size_t)(si ? gr.n[0] : 0) * rsz;
         J.s64 = se.xyz64;
         J.row_base = res.begin;
@@ -1172,9 +1242,10 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         // one store) and the reductions form distance and row-indexed projection from rows and normals they read in row order
         // (NNOut::layout).  PCCM_DEFER=0: the searches form both themselves, as in round 2 (A/B runs)
         static const bool defer_off = [] { const char *e = getenv("PCCM_DEFER"); return e && e[0] == '0'; }();
-        const bool defer = !defer_off && gr.rec32 && fm != PCCM_NORMAL_NEIGHBOUR;
+        const bool defer = gr.vox || (!defer_off && gr.rec32 && fm != PCCM_NORMAL_NEIGHBOUR);
         if (defer) res.rec_stride = 2;
         res.rec_layout = defer ? 1 : 0;
+        res.no_rows = gr.vox;
         J.out.rec = (double *)res.rec.p;
         J.out.stride = res.rec_stride;
         J.out.nrm = fm >= 0 ? se.nrm64 : nullptr;
@@ -1248,7 +1319,15 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
             nqmax = jobs.j[k].nq > nqmax ? jobs.j[k].nq : nqmax;
         }
         const int64_t qblocks = (nqmax + 255) / 256;
-        if (use_coop(ctx)) {
+        if (gr.vox) {
+            {
+                ProfScope ps(ctx, PCCM_K_GRID_QUERY);
+                if ((rc = launch_vox_query(ctx, jobs, g, self))) return rc;
+            }
+            ProfScope pf(ctx, PCCM_K_GRID_FINISH);             // queries with nothing within 8 voxels: the general search
+            dim3 tgrid((unsigned)(qblocks < 1024 ? qblocks : 1024));
+            launch_queries<Rec32>(ctx, jobs, g, self, false, tgrid);
+        } else if (use_coop(ctx)) {
             {
                 ProfScope ps(ctx, PCCM_K_GRID_QUERY);
                 if (gr.rec32) {

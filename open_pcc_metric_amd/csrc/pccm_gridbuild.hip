@@ -535,6 +535,13 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
     // is sorted from registers; 2^11 cells at 8M + 8M points meant streaming every bin twice (585 instead of 503 us per build)
     int lg = ceil_log2((ncells + 8191) / 8192);
     P.lg = lg < 10 ? 10 : (lg > kMaxLg ? kMaxLg : lg);
+    // crowded cells (voxel-brick grids: 8^3 voxels per cell, dozens of points in an occupied one): smaller bins, so that a bin
+    // still fits the register path of k_bin_sort and there are enough of them to fill the chip
+    {
+        int64_t nmax = 0;
+        for (int k = 0; k < jobs.njobs; ++k) nmax = jobs.j[k].n > nmax ? jobs.j[k].n : nmax;
+        while (P.lg > 6 && (double)nmax * (double)(1ll << P.lg) / (double)ncells > 2000.0 && ((ncells >> (P.lg - 1)) + 1) <= 8192) --P.lg;
+    }
     static const int lg_env = [] { const char *e = getenv("PCCM_BUILD_LG"); return e ? atoi(e) : 0; }();
     if (lg_env >= 8 && lg_env <= kMaxLg && (ncells >> lg_env) < 8192) P.lg = lg_env;
     P.nbin = (int)((ncells + (1ll << P.lg) - 1) >> P.lg);

@@ -75,6 +75,7 @@ struct NNResult {
     int rec_stride = 4;         // doubles per record: 4 = with the matched row, 2 = {d2, projection} only (pccm_nn_want_idx off)
     int rec_layout = 0;         // 0: {d2, projection[, row, -]}; 1 (stride 2): the matched record {rx, ry, rz, row}: distance and
                                 //    row-indexed projection are formed by the reduction that reads the records (NNOut::layout)
+    bool no_rows = false;       // layout 1 records whose row word is void (voxel-brick search): good for distances only
     int64_t stats[3] = {0, 0, 0};
     uint32_t *nflag_dev = nullptr;  // device counters of the last run: [0] fallback queries, [1] grid tail length
     DevBuf flagged, flag_thr;       // queries handed to the exact rescan (k2b_fallback) and their thresholds
@@ -130,6 +131,11 @@ struct Grid {                    // one geometry, both clouds (grid engine)
     bool lattice = false;          // voxelised pair on the per-thread path: pccm_lattice.hip searches it, with the bitmap below
     DevBuf occ;                    // uint32 [2][ncells / 32 + 2]: one bit per cell, set when the cell holds a record
     DevBuf recs;                   // GridRec or Rec32 [n[0] + n[1]]: cloud 0's records, then cloud 1's
+    bool vox = false;              // voxel-brick flavour (pccm_vox.hip): cells of 8^3 voxels, searched through the bricks below;
+                                   // built for distance-only requests on voxelised pairs, rebuilt with the usual cells otherwise
+    DevBuf vbricks;                // uint32 [n[0] + n[1]][32]: occupancy + duplicate brick at the index of a cell's first record
+    DevBuf vlist;                  // uint32 [n[0] + n[1]]: occupied cells of cloud 0, then (from n[0]) of cloud 1
+    DevBuf vcount;                 // uint32 [2]
 };
 
 struct ReduceSlot {            // one enqueued reduction (pccm_reduce_prefetch / pccm_reduce)
@@ -156,6 +162,7 @@ struct GraphOp {               // host-side effect of one captured call, replaye
     int dir = 0, slot = -1;
     bool rec_valid = false, plain_valid = false;   // kind 1: where the direction's results live once the graph has run
     int fused_mode = -1, rec_stride = 4, rec_layout = 0;
+    bool no_rows = false;
     ReduceSlot snap;           // kind 2: the slot's bookkeeping at capture time (pointers are not owned)
 };
 

@@ -1,0 +1,288 @@
+// Voxel-brick search for VOXELISED content on gfx950 when only DISTANCES are asked for (D1 MSE / PSNR / Hausdorff, the
+// intrinsic resolution): both clouds integer-valued (every PCC test sequence: 8i, Owlii, MVUB -- BASELINE.json configs[4]).
+//
+// Stands under get_neighbour_cloud(), open_pcc_metric/cloud_pair.py:10-42, for the callers that read nothing but the squared
+// distances of its result (cloud_pair.py:102-106 -> metric.py:213-247, 353-386).  Whoever needs the matched ROW (colour
+// metrics, error vectors, D2 projections: an exact tie decides which neighbour's row / error vector is taken) gets the
+// per-thread lattice search (pccm_lattice.hip) on a grid of its own cell size: the library repeats the search then, as it does
+// for pccm_nn_want_idx (include/pccm.h).
+//
+// The pair's grid has cells of exactly 8 x 8 x 8 voxels here (origin on the integer lattice), and every occupied cell of a
+// cloud owns a 512-bit occupancy BRICK (bit x + 8 y + 64 z; k_vox_bricks, one pass over the cell-sorted records) plus a brick of
+// the voxels that hold more than one point (the self search's "another point at distance 0").  One wave serves one occupied
+// cell of the iterating cloud:
+//   1. 36 lanes fetch the cell starts of the 3 x 3 x-runs around the cell (which of the 27 cells hold anything, and where their
+//      bricks are: a brick lives at the index of its cell's first record -- no slot table, nothing to clear),
+//   2. the occupied ones' bricks (64 bytes each) and the cell's queries are fetched together,
+//   3. the 27 bricks are transposed in LDS into 24 x 24 x-rows of 24 bits, one word per (y, z),
+//   4. every lane takes a query and walks the (dy, dz) rows in order of dy^2 + dz^2 (a 197-entry table in scalar memory: the
+//      walk is wave-uniform), per row ONE LDS word and a handful of bit instructions: nearest set bit on either side of the
+//      query's x (v_ffbl / v_ffbh), d2 = dx^2 + dy^2 + dz^2 -- integers: exact, no certification -- until dy^2 + dz^2 reaches
+//      the best d2 so far.
+// A best d2 <= 64 is final: every voxel within 8 of a query of the cell lies inside the staged 24^3.  Anything farther (or
+// nothing found) goes to the tail list and through the general kernels (k_grid_finish -> k2b_fallback), like the brick kernel's.
+// Results are matched records {x, y, z of the nearest voxel, row -1} (NNOut::layout 1): the reductions form the distance.
+// Bound: the launch is short and latency-bound (two dependent round trips per wave, thousands of waves in flight); the per-row
+// walk is ~12 VALU instructions.
+#include "pccm_grid.h"
+
+namespace pccm {
+
+constexpr int kVoxRowsPadded = 200;                 // 197 rows + padding
+// (dy^2 + dz^2) << 16 | (dy + 8) << 8 | (dz + 8), sorted: every (dy, dz) with dy^2 + dz^2 <= 64
+__constant__ __attribute__((aligned(16))) uint32_t c_vox_rows[kVoxRowsPadded] = {
+    0x808, 0x10708, 0x10807, 0x10809, 0x10908, 0x20707, 0x20709, 0x20907, 0x20909, 0x40608, 0x40806, 0x4080a, 0x40a08, 0x50607, 0x50609,
+    0x50706, 0x5070a, 0x50906, 0x5090a, 0x50a07, 0x50a09, 0x80606, 0x8060a, 0x80a06, 0x80a0a, 0x90508, 0x90805, 0x9080b, 0x90b08, 0xa0507,
+    0xa0509, 0xa0705, 0xa070b, 0xa0905, 0xa090b, 0xa0b07, 0xa0b09, 0xd0506, 0xd050a, 0xd0605, 0xd060b, 0xd0a05, 0xd0a0b, 0xd0b06, 0xd0b0a,
+    0x100408, 0x100804, 0x10080c, 0x100c08, 0x110407, 0x110409, 0x110704, 0x11070c, 0x110904, 0x11090c, 0x110c07, 0x110c09, 0x120505, 0x12050b,
+    0x120b05, 0x120b0b, 0x140406, 0x14040a, 0x140604, 0x14060c, 0x140a04, 0x140a0c, 0x140c06, 0x140c0a, 0x190308, 0x190803, 0x19080d, 0x190d08,
+    0x190405, 0x19040b, 0x190504, 0x19050c, 0x190b04, 0x190b0c, 0x190c05, 0x190c0b, 0x1a0307, 0x1a0309, 0x1a0703, 0x1a070d, 0x1a0903, 0x1a090d,
+    0x1a0d07, 0x1a0d09, 0x1d0306, 0x1d030a, 0x1d0603, 0x1d060d, 0x1d0a03, 0x1d0a0d, 0x1d0d06, 0x1d0d0a, 0x200404, 0x20040c, 0x200c04, 0x200c0c,
+    0x220305, 0x22030b, 0x220503, 0x22050d, 0x220b03, 0x220b0d, 0x220d05, 0x220d0b, 0x240208, 0x240802, 0x24080e, 0x240e08, 0x250207, 0x250209,
+    0x250702, 0x25070e, 0x250902, 0x25090e, 0x250e07, 0x250e09, 0x280206, 0x28020a, 0x280602, 0x28060e, 0x280a02, 0x280a0e, 0x280e06, 0x280e0a,
+    0x290304, 0x29030c, 0x290403, 0x29040d, 0x290c03, 0x290c0d, 0x290d04, 0x290d0c, 0x2d0205, 0x2d020b, 0x2d0502, 0x2d050e, 0x2d0b02, 0x2d0b0e,
+    0x2d0e05, 0x2d0e0b, 0x310108, 0x310801, 0x31080f, 0x310f08, 0x320107, 0x320109, 0x320701, 0x32070f, 0x320901, 0x32090f, 0x320f07, 0x320f09,
+    0x320303, 0x32030d, 0x320d03, 0x320d0d, 0x340204, 0x34020c, 0x340402, 0x34040e, 0x340c02, 0x340c0e, 0x340e04, 0x340e0c, 0x350106, 0x35010a,
+    0x350601, 0x35060f, 0x350a01, 0x350a0f, 0x350f06, 0x350f0a, 0x3a0105, 0x3a010b, 0x3a0501, 0x3a050f, 0x3a0b01, 0x3a0b0f, 0x3a0f05, 0x3a0f0b,
+    0x3d0203, 0x3d020d, 0x3d0302, 0x3d030e, 0x3d0d02, 0x3d0d0e, 0x3d0e03, 0x3d0e0d, 0x400008, 0x400800, 0x400810, 0x401008,
+    0xffff0808, 0xffff0808, 0xffff0808       // padding to whole quadruples: rows nobody can want (row (0, 0) again, at a distance beyond reach)
+};
+
+// The occupied cells of every job in cell order, from the occupancy bitmap the build has written: one workgroup per job, every
+// thread a run of bitmap words (all of them in flight at once: the kernel is two memory round trips and a block scan).
+// (No counter is contended: see k_vox_bricks.  As an extra workgroup of k_vox_bricks' grid, with 256 threads, it was that
+// kernel's long pole: 29 us.)
+__global__ __launch_bounds__(1024) void k_vox_list(VoxBuild vb)
+{
+    __shared__ uint32_t s_w[16];
+    const VoxBuildJob &J = vb.j[blockIdx.x];
+    const int64_t ncells = vb.ncells;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t nwords = (ncells + 31) / 32;
+    const uint32_t last_mask = (ncells & 31) ? (1u << (ncells & 31)) - 1u : 0xffffffffu;      // (bits beyond the grid are not cells)
+    const int64_t per = (nwords + 1023) / 1024;
+    const int64_t w0 = (int64_t)tid * per, w1 = (w0 + per < nwords) ? w0 + per : nwords;
+    uint32_t cnt = 0u;
+    for (int64_t k0 = w0; k0 < w1; k0 += 8) {
+        uint32_t bits[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bits[u] = (k0 + u < w1) ? J.occ[k0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cnt += (uint32_t)__popc(k0 + u == nwords - 1 ? bits[u] & last_mask : bits[u]);
+    }
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t pos = inc - cnt;
+    for (int k = 0; k < w; ++k) pos += s_w[k];
+    if (tid == 1023) *J.count = pos + cnt;
+    for (int64_t k0 = w0; k0 < w1; k0 += 8) {
+        uint32_t bits[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bits[u] = (k0 + u < w1) ? J.occ[k0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t b = k0 + u == nwords - 1 ? bits[u] & last_mask : bits[u];
+            while (b) {
+                J.list[pos++] = (uint32_t)((k0 + u) * 32 + __builtin_ctz(b));
+                b &= b - 1u;
+            }
+        }
+    }
+}
+
+// One workgroup per tile of 64 consecutive cells of a job's grid (their records are one contiguous piece of the cell-sorted
+// array): the occupancy brick and the duplicate brick of every occupied cell, OR-ed together in LDS and written at the index of
+// the cell's first record.  Empty tiles leave after one look at their cell starts.  (A list of the occupied cells for the
+// search to walk is NOT appended here: appends through one device-scope counter -- one per cell, or one per tile -- cost 45 us,
+// returning atomics on one address from eight XCDs serialise at memory.  k_vox_list makes it from the occupancy bitmap.)
+constexpr int kVoxTile = 64;
+__global__ __launch_bounds__(256) void k_vox_bricks(VoxBuild vb, GridGeom g)
+{
+    __shared__ uint32_t s_b[kVoxTile * 32];
+    __shared__ uint32_t s_cs[kVoxTile + 1];
+    const VoxBuildJob &J = vb.j[blockIdx.y];
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * kVoxTile;
+    const int nc = (int)((c0 + kVoxTile < vb.ncells ? c0 + kVoxTile : vb.ncells) - c0);
+    if (tid <= nc) s_cs[tid] = J.cs[c0 + tid];
+    for (int k = tid; k < kVoxTile * 32; k += 256) s_b[k] = 0u;
+    __syncthreads();
+    const uint32_t s = s_cs[0], e = s_cs[nc];
+    if (e <= s) return;                                   // (block-uniform)
+    const int dimx = g.dim[0], dimy = g.dim[1];
+    const int gox = (int)g.org[0], goy = (int)g.org[1], goz = (int)g.org[2];
+    const float4 *recs = reinterpret_cast<const float4 *>(J.recs);
+    for (uint32_t p = s + (uint32_t)tid; p < e; p += 256u) {
+        const float4 r = recs[p];
+        const int x = (int)r.x - gox, y = (int)r.y - goy, z = (int)r.z - goz;        // >= 0: the origin is the box's lower corner
+        const int64_t lin = ((int64_t)(z >> 3) * dimy + (y >> 3)) * dimx + (x >> 3) - c0;   // 0 .. nc - 1: the records are cell-sorted
+        const int v = (x & 7) + 8 * (y & 7) + 64 * (z & 7);
+        uint32_t *b = s_b + (int)lin * 32;
+        const uint32_t bit = 1u << (v & 31);
+        const uint32_t old = atomicOr(&b[v >> 5], bit);
+        if (old & bit) atomicOr(&b[16 + (v >> 5)], bit);
+    }
+    __syncthreads();
+    for (int k = tid; k < nc * 32; k += 256) {
+        const int j = k >> 5;
+        const uint32_t a = s_cs[j];
+        if (s_cs[j + 1] > a) J.bricks[(size_t)a * 32 + (k & 31)] = s_b[k];
+    }
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
+{
+    __shared__ uint32_t s_cs[40];                 // 9 rows x 4 cell starts of the searched cloud, [36], [37]: the cell's query range
+    __shared__ uint32_t s_brick[27 * 16];         // occupancy bricks of the 27 cells (zero: empty / outside)
+    __shared__ uint32_t s_rows[576];              // x-rows of the staged 24^3: bit x + 1 of word [Y * 24 + Z]
+    __shared__ uint32_t s_dup[16];                // SELF: the cell's own voxels that hold more than one point
+    const QueryJob &J = jobs.j[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
+    const uint32_t count = *J.vcount;
+    const float4 *__restrict__ qrecs = reinterpret_cast<const float4 *>(J.qrecs);
+    const uint32_t *__restrict__ cs = J.cs;
+    const int gox = (int)g.org[0], goy = (int)g.org[1], goz = (int)g.org[2];
+    const uint4 *__restrict__ tab = reinterpret_cast<const uint4 *>(c_vox_rows);
+    // one wave per workgroup, one occupied cell of the iterating cloud per turn (a wave's LDS operations execute in order: the
+    // barriers below are scheduling fences only)
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint32_t c = J.vlist[it];
+        const uint32_t cyz = c / (uint32_t)dimx;
+        const int cx = (int)(c - cyz * (uint32_t)dimx), cy = (int)(cyz % (uint32_t)dimy), cz = (int)(cyz / (uint32_t)dimy);
+        // ---- 1. cell starts of the 3 x 3 x-runs (cells cx - 1 .. cx + 1, and the end of the last) + the cell's query range -----
+        if (lane < 36) {
+            const int r = lane >> 2, k = lane & 3;
+            const int y = cy + r % 3 - 1, z = cz + r / 3 - 1, x = cx - 1 + k;
+            uint32_t v = 0u;
+            if (y >= 0 && y < dimy && z >= 0 && z < dimz && x >= 0 && x <= dimx) v = cs[((uint32_t)z * dimy + y) * dimx + x];
+            s_cs[lane] = v;
+        } else if (lane < 38) {
+            s_cs[lane] = J.qcs[c + (uint32_t)(lane - 36)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t q0 = s_cs[36], nq = s_cs[37] - q0;
+        // ---- 2. bricks (a quarter-brick per lane and pass) and the first 64 queries, all in flight together -----------------
+        for (int t = lane; t < 27 * 4; t += 64) {
+            const int b = t >> 2, part = t & 3;
+            const int r = b / 3, k = b - 3 * r;
+            const int y = cy + r % 3 - 1, z = cz + r / 3 - 1, x = cx - 1 + k;
+            uint4 w = make_uint4(0u, 0u, 0u, 0u), d = w;
+            if (y >= 0 && y < dimy && z >= 0 && z < dimz && x >= 0 && x < dimx) {
+                const uint32_t s = s_cs[r * 4 + k], e = s_cs[r * 4 + k + 1];
+                if (e > s) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(J.vbricks + (size_t)s * 32);
+                    w = src[part];
+                    if (SELF && b == 13) d = src[4 + part];          // (a query's own voxel lies in the cell itself)
+                }
+            }
+            reinterpret_cast<uint4 *>(s_brick)[t] = w;
+            if (SELF && b == 13) reinterpret_cast<uint4 *>(s_dup)[part] = d;
+        }
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((uint32_t)lane < nq) q = qrecs[q0 + lane];
+        __builtin_amdgcn_wave_barrier();
+        // ---- 3. transpose: x-row (Y, Z) of the 24^3 = one byte of each of three bricks (rows lane, lane + 64, ...: Y and Z
+        //         advance by 2 and 16) ---------------------------------------------------------------------------------------
+        {
+            const unsigned char *bb = reinterpret_cast<const unsigned char *>(s_brick);
+            int Y = lane / 24, Z = lane - 24 * Y;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int b0 = ((Y >> 3) + 3 * (Z >> 3)) * 192 + (Y & 7) + 8 * (Z & 7);
+                // bits 1 .. 24 = voxels x = 0 .. 23; bits 0 and 25 are sentinels ("points" at x = -1 and x = 24: at least 9 away from
+                // every query of the cell, i.e. beyond the 8 this search vouches for): the bit scans below never see an empty word
+                s_rows[lane + 64 * j] = ((uint32_t)bb[b0] << 1) | ((uint32_t)bb[b0 + 64] << 9) | ((uint32_t)bb[b0 + 128] << 17) | 0x2000001u;
+                Y += 2;
+                Z += 16;
+                if (Z >= 24) { Z -= 24; Y += 1; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- 4. queries --------------------------------------------------------------------------------------------------
+        const int rx0 = gox + 8 * (cx - 1), ry0 = goy + 8 * (cy - 1), rz0 = goz + 8 * (cz - 1);      // voxel (0, 0, 0) of the 24^3
+        for (uint32_t qb = 0; qb < nq; qb += 64u) {
+            const bool have = qb + (uint32_t)lane < nq;
+            if (qb) q = have ? qrecs[q0 + qb + lane] : q;
+            const int lx = have ? (int)q.x - rx0 : 8, ly = have ? (int)q.y - ry0 : 8, lz = have ? (int)q.z - rz0 : 8;   // 8 .. 15
+            const int base = ly * 24 + lz;
+            const int L = lx + 1;                           // the query's bit in a row word
+            const uint32_t below = (1u << L) - 1u;
+            uint32_t own = 0xffffffffu;
+            if (SELF) {                                     // the query's own voxel counts only when it holds another point
+                const int v = (lx - 8) + 8 * (ly - 8) + 64 * (lz - 8);
+                own = ((s_dup[v >> 5] >> (v & 31)) & 1u) ? 0xffffffffu : ~(1u << L);
+            }
+            // best = d2 << 8 | table index of the row it was found in; an idle lane starts settled
+            uint32_t best = have ? 0xffffffffu : 0u;
+            // rows four at a time (the table is padded to whole quadruples): one scalar load, four LDS reads in flight
+            for (int k4 = 0; k4 < kVoxRowsPadded / 4; ++k4) {
+                const uint4 e4 = tab[k4];
+                if (__ballot((best >> 8) > (e4.x >> 16)) == 0ull) break;   // every lane's best is within reach of the rows done
+                const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+                uint32_t w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int off = ((int)((ee[u] >> 8) & 0xffu) - 8) * 24 + ((int)(ee[u] & 0xffu) - 8);
+                    w[u] = s_rows[base + off];
+                }
+                if (SELF && k4 == 0) w[0] &= own;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // nearest set bit at or above L, and below it: both scans see a sentinel at worst (v_ffbl_b32 / v_ffbh_u32)
+                    const uint32_t up = (uint32_t)__builtin_ctz(w[u] >> L);
+                    const uint32_t dn = (uint32_t)(__builtin_clz(w[u] & below) + L - 31);
+                    const uint32_t dx = up < dn ? up : dn;
+                    const uint32_t key = ((dx * dx + (ee[u] >> 16)) << 8) | (uint32_t)(4 * k4 + u);
+                    best = key < best ? key : best;
+                }
+            }
+            if (have) {
+                const uint32_t d2 = best >> 8;
+                const int qrow = __float_as_int(q.w);
+                if (d2 <= 64u) {
+                    // the winning row again: which side, how far
+                    const uint32_t e = c_vox_rows[best & 0xffu];
+                    const int dy = (int)((e >> 8) & 0xffu) - 8, dz = (int)(e & 0xffu) - 8;
+                    uint32_t w = s_rows[base + dy * 24 + dz];
+                    if (SELF && (best & 0xffu) == 0u) w &= own;
+                    const int up = __builtin_ctz(w >> L), dn = __builtin_clz(w & below) + L - 31;
+                    const int mx = dn < up ? lx - dn : lx + up;
+                    store_result_rec(J.out, qrow, (float)(rx0 + mx), (float)(ry0 + ly + dy), (float)(rz0 + lz + dz), -1);
+                } else {
+                    const uint32_t pos = atomicAdd(&J.counters[1], 1u);
+                    reinterpret_cast<float4 *>(J.tail)[pos] = q;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                     // the next cell overwrites the staging
+    }
+}
+
+int launch_vox_bricks(pccm_ctx *ctx, const VoxBuild &vb, const GridGeom &g)
+{
+    dim3 grid((unsigned)((vb.ncells + kVoxTile - 1) / kVoxTile), (unsigned)vb.njobs);
+    hipLaunchKernelGGL(k_vox_bricks, grid, dim3(256), 0, ctx->stream, vb, g);
+    hipLaunchKernelGGL(k_vox_list, dim3((unsigned)vb.njobs), dim3(1024), 0, ctx->stream, vb);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+int launch_vox_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self)
+{
+    // one wave per occupied cell and turn, 32 waves per CU resident: a fixed grid walks the list (its length lives on the device)
+    dim3 grid(8192u, (unsigned)jobs.njobs);
+    if (self) hipLaunchKernelGGL((k_vox_query<true>), grid, dim3(64), 0, ctx->stream, jobs, g);
+    else hipLaunchKernelGGL((k_vox_query<false>), grid, dim3(64), 0, ctx->stream, jobs, g);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+}  // namespace pccm

@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     {"PCCM_SPATIAL": "0"},                                    # round 3: grid builds from the caller's row order
     {"PCCM_DEFER": "0"},                                      # ... searches that store {d2, projection} and gather normals themselves
     {"PCCM_LATTICE": "0"},                                    # ... voxelised pairs on the general per-thread kernel
+    {"PCCM_VOX": "0"},                                        # ... voxelised pairs on the per-thread lattice kernel (no voxel bricks)
     {"PCCM_DEFER": "0", "PCCM_SPATIAL": "0", "PCCM_NRM32": "0"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_ab_path_gives_the_same_report(env):

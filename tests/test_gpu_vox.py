@@ -1,0 +1,87 @@
+"""The voxel-brick search (open_pcc_metric_amd/csrc/pccm_vox.hip): voxelised pairs whose callers read distances only
+(cloud_pair.py:102-106 -> metric.py:213-247, 353-386 of the reference).  Against the oracle, bit for bit:
+
+* squared distances of both directions and of the self search (the intrinsic resolution) on content with duplicates
+  inside a cloud (the self search's "another point at distance 0"), negative coordinates, points farther than the
+  8 voxels the bricks vouch for (the tail kernels take those) and clouds of different sizes;
+* whoever asks for matched rows afterwards (nn indices, error vectors, point-to-plane with neighbour normals) gets the
+  searched-with-rows answer: the library repeats the search on a grid of its usual cell size (include/pccm.h,
+  pccm_nn_want_idx);
+* PCCM_VOX=0 (the per-thread lattice search) gives the same numbers: tests/test_gpu_ab_paths.py."""
+import numpy as np
+import pytest
+
+from open_pcc_metric_amd.calculator import MetricCalculator
+from open_pcc_metric_amd.cloud_pair import CloudPair
+from open_pcc_metric_amd.options import CalculateOptions, transform_options
+from open_pcc_metric_amd.point_cloud import PointCloud
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def shell(n, seed, centre, radius, jitter=0.0, dup=0, far=0):
+    """Integer points on a sphere shell, optionally jittered, with `dup` repeated points and `far` stray points."""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    p = np.round(np.asarray(centre) + radius * v + rng.normal(0, jitter, (n, 3)))
+    p = np.unique(p, axis=0)
+    if dup:
+        p = np.concatenate([p, p[rng.integers(0, len(p), dup)]])
+    if far:
+        p = np.concatenate([p, np.round(np.asarray(centre) + rng.uniform(-2.2, 2.2, (far, 3)) * radius)])
+    return np.ascontiguousarray(p[rng.permutation(len(p))].astype(np.float32))
+
+
+CASES = {
+    "shell_dups_strays": (shell(90_000, 1, (40, -15, 7), 120, dup=500, far=40), shell(70_000, 2, (41, -15, 6), 121, 0.6, dup=300, far=25)),
+    "small_unequal": (shell(3_000, 3, (0, 0, 0), 30, dup=10), shell(900, 4, (1, 1, -1), 33, 0.8)),
+    "far_apart": (shell(5_000, 5, (0, 0, 0), 25), shell(5_000, 6, (90, 0, 0), 25)),       # nothing within 8 voxels: all tails
+    "one_cell": (shell(200, 7, (3, 3, 3), 3, dup=20), shell(150, 8, (3, 3, 3), 3, 0.5)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_vox_distances_match_oracle(name):
+    a, b = CASES[name]
+    want_l, dl = orc.nn(a, b, method="kdtree")
+    _, dr = orc.nn(b, a, method="kdtree")
+    _, ds = orc.nn(a, a, skip_same_index=True, method="kdtree")
+    with CloudPair(PointCloud(a), PointCloud(b), extent=[300.0, 300.0, 300.0], device=0) as pair:
+        for _ in range(2):                                   # a first search, then a rebuild after pccm_drop_caches
+            pair.recompute()
+            eng = pair._engine
+            eng.nn(2)                                        # the self search (the intrinsic resolution, metric.py:187-188)
+            # the grid these searches ran on is the voxel-brick one: cells of 8 x 8 x 8 voxels over the pair's bounding box
+            lo, hi = np.minimum(a.min(0), b.min(0)), np.maximum(a.max(0), b.max(0))
+            assert eng.nn_stats(0)["splits"] == int(np.prod(np.floor((hi - lo) / 8.0) + 1))
+            for direction, want in ((0, dl), (1, dr), (2, ds)):
+                _, got = eng.fetch_nn(direction, want_idx=False)
+                assert np.array_equal(got, want), f"{name}: direction {direction}: {int(np.sum(got != want))} of {len(want)} squared distances differ"
+        # ... and now somebody wants the rows: same distances, indices of equidistant-or-not neighbours that reproduce them
+        idx, got = eng.fetch_nn(0, want_idx=True)
+        assert np.array_equal(got, dl)
+        assert np.array_equal(np.sum((a.astype(np.float64) - b.astype(np.float64)[idx]) ** 2, axis=1), dl)
+        assert np.array_equal(idx, want_l), "ties go to the smallest row (include/pccm.h)"
+
+
+def test_vox_report_then_d2():
+    """A distances-only report through the voxel bricks, then point-to-plane on the same pair (normals arrive late): the D2 rows
+    need the matched rows / error vectors, the library searches again."""
+    a, b = CASES["shell_dups_strays"]
+    rng = np.random.default_rng(9)
+    na = rng.standard_normal(a.shape).astype(np.float32)
+    nb = rng.standard_normal(b.shape).astype(np.float32)
+    want1 = orc.OraclePair(a, b, None, None, method="kdtree").report(hausdorff=True, point_to_plane_=False, peak=300.0)
+    with CloudPair(PointCloud(a), PointCloud(b), extent=[300.0, 300.0, 300.0], device=0) as pair:
+        pair.recompute()
+        got1 = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, False))).as_dict()
+        for key, val in want1.items():
+            assert got1[key] == val, key
+    want2 = orc.OraclePair(a, b, na, nb, method="kdtree", normal_index="neighbour").report(hausdorff=True, point_to_plane_=True, peak=300.0)
+    with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[300.0, 300.0, 300.0], device=0, normal_index="neighbour") as pair:
+        pair.recompute()
+        got2 = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, True))).as_dict()
+        for key, val in want2.items():
+            assert got2[key] == val, key
