@@ -235,7 +235,8 @@ def main():
                     "points": [len(ca), len(cb)], "kernel_us_per_step": kus, "grid_cells": ce.nn_stats(0)["splits"],
                     "mse_left": float(cres[("GeoMSE", True, False)]),
                     "note": "10-bit voxelised closed surface vs a jittered / thinned copy (BASELINE configs[4]-class content; the real "
-                            "longdress files are not in the container), D1 MSE / PSNR / Hausdorff, both directions + symmetric"}
+                            "longdress files are not in the container), D1 MSE / PSNR / Hausdorff, both directions + symmetric; "
+                            "distances only, so the searches run on the voxel bricks (pccm_vox.hip; PCCM_VOX=0: the per-thread lattice kernel)"}
 
     if args.content_only:
         print(json.dumps({"content": content_record(args.steps or 50)}), flush=True)
@@ -348,7 +349,10 @@ def main():
                     "kernel": "k_brick_query (ring-1 search of both directions, one launch; results = matched records)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": gq_n, "algorithmic_bytes_per_launch": alg_bytes,
                     "compulsory_bytes_per_launch": compulsory, "traffic_note": traffic_note,
-                    "arithmetic": "fp32 candidate filter in LDS, fp64 decisions and outputs"}
+                    "arithmetic": "fp32 candidate filter in LDS (packed fp32, 13 VALU instructions per pair of candidates), fp32 stop rule",
+                    "limiter": "vector-ALU issue, not HBM: PMC (profiles/r03) counts ~930 VALU instructions per wave, 33 120 waves -> "
+                               "~120 k issue clocks per SIMD of the launch's ~150-170 k; more workgroups per CU, conflict-free LDS reads "
+                               "and fewer memory round trips each left the time unchanged, fewer instructions shortened it in proportion"}
 
     reduce_roofline = None
     red_ms, red_n = eng.profile_get("reduce")

@@ -538,8 +538,10 @@ static BrickShape brick_shape()
 }
 
 // plane sizes the kernels are compiled for: the small one holds the bricks of whole clouds at ~1.4 points per cell with four
-// workgroups per CU (4 x 2176 floats + 3.6 KB of tables = 38.4 KB), the large one is the 64 KB workgroup limit
-constexpr int kPlaneTight = 1728, kPlaneSmall = 2176, kPlaneLarge = 3584;
+// workgroups per CU (4 x 2176 floats + 3.6 KB of tables = 38.4 KB), the middle one the 4 x 4-row bricks of sharded ranks with
+// three (4 x 3008 floats + 5.4 KB = 53.6 KB -- 3040 floats no longer fit three times; with the large one -- two per CU -- a rank's search took 40 instead of 32 us at
+// 1M points / 8 ranks), the large one is the 64 KB workgroup limit
+constexpr int kPlaneTight = 1728, kPlaneSmall = 2176, kPlaneMid = 3008, kPlaneLarge = 3584;
 
 template <int BY, int BZ, int PL>
 static void launch_plane(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density_q, int force_nt)
@@ -637,7 +639,8 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     // LDS budget: the expected number of staged records (runs x cells x points per cell) plus a quarter -- occupancy
     // is set by it.  Bricks that hold more (clumped data) hand their queries to the general kernels.
     const double expect = (double)((BY + 2) * (BZ + 2)) * (bp.bx + 2) * density_s;
-    int cap = (int)(1.25 * expect) + 64;
+    const double margin = fmin(0.25 * expect, 8.0 * sqrt(expect));      // a quarter, or eight sigma of a Poisson count
+    int cap = (int)(expect + margin) + 64;
     static const int cap_env = [] { const char *e = getenv("PCCM_BRICK_CAP"); return e ? atoi(e) : 0; }();
     if (cap_env > 0) cap = cap_env;
     if (cap < 256) cap = 256;
@@ -649,6 +652,9 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     } else if (cap + 2 <= kPlaneSmall) {
         bp.cap = kPlaneSmall - 2;
         launch_plane<BY, BZ, kPlaneSmall>(ctx, jobs, g, self, bp, density_q, force_nt);
+    } else if (cap + 2 <= kPlaneMid) {
+        bp.cap = kPlaneMid - 2;
+        launch_plane<BY, BZ, kPlaneMid>(ctx, jobs, g, self, bp, density_q, force_nt);
     } else {
         bp.cap = kPlaneLarge - 2;
         launch_plane<BY, BZ, kPlaneLarge>(ctx, jobs, g, self, bp, density_q, force_nt);

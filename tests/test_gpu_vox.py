@@ -20,7 +20,7 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def shell(n, seed, centre, radius, jitter=0.0, dup=0, far=0):
+def shell(n, seed, centre, radius, jitter=0.0, dup=0, far=0, reach=1.4):
     """Integer points on a sphere shell, optionally jittered, with `dup` repeated points and `far` stray points."""
     rng = np.random.default_rng(seed)
     v = rng.standard_normal((n, 3))
@@ -30,14 +30,18 @@ def shell(n, seed, centre, radius, jitter=0.0, dup=0, far=0):
     if dup:
         p = np.concatenate([p, p[rng.integers(0, len(p), dup)]])
     if far:
-        p = np.concatenate([p, np.round(np.asarray(centre) + rng.uniform(-2.2, 2.2, (far, 3)) * radius)])
+        p = np.concatenate([p, np.round(np.asarray(centre) + rng.uniform(-reach, reach, (far, 3)) * radius)])
     return np.ascontiguousarray(p[rng.permutation(len(p))].astype(np.float32))
 
 
 CASES = {
     "shell_dups_strays": (shell(90_000, 1, (40, -15, 7), 120, dup=500, far=40), shell(70_000, 2, (41, -15, 6), 121, 0.6, dup=300, far=25)),
+    # outliers that more than double the bounding box: the grid covers the quantile box (decide_scale), which the bricks do not
+    # support -- the per-thread lattice kernel then
+    "boxed_outliers": (shell(60_000, 11, (0, 0, 0), 100, far=30, reach=2.6), shell(50_000, 12, (1, 0, 0), 100, 0.6, far=20, reach=2.6)),
     "small_unequal": (shell(3_000, 3, (0, 0, 0), 30, dup=10), shell(900, 4, (1, 1, -1), 33, 0.8)),
-    "far_apart": (shell(5_000, 5, (0, 0, 0), 25), shell(5_000, 6, (90, 0, 0), 25)),       # nothing within 8 voxels: all tails
+    "far_apart": (shell(5_000, 5, (0, 0, 0), 25), shell(5_000, 6, (90, 0, 0), 25)),       # nothing in common: the brute-force engine
+    "holes": (shell(40_000, 9, (0, 0, 0), 80), shell(40_000, 10, (0, 0, 0), 80)[:16_000]),  # most of B missing: tails beyond 8 voxels
     "one_cell": (shell(200, 7, (3, 3, 3), 3, dup=20), shell(150, 8, (3, 3, 3), 3, 0.5)),
 }
 
@@ -54,8 +58,10 @@ def test_vox_distances_match_oracle(name):
             eng = pair._engine
             eng.nn(2)                                        # the self search (the intrinsic resolution, metric.py:187-188)
             # the grid these searches ran on is the voxel-brick one: cells of 8 x 8 x 8 voxels over the pair's bounding box
-            lo, hi = np.minimum(a.min(0), b.min(0)), np.maximum(a.max(0), b.max(0))
-            assert eng.nn_stats(0)["splits"] == int(np.prod(np.floor((hi - lo) / 8.0) + 1))
+            # (clouds with nothing in common are the exception: PCCM_ENGINE_AUTO hands such a pair to the brute-force engine)
+            if name not in ("far_apart", "boxed_outliers"):
+                lo, hi = np.minimum(a.min(0), b.min(0)), np.maximum(a.max(0), b.max(0))
+                assert eng.nn_stats(0)["splits"] == int(np.prod(np.floor((hi - lo) / 8.0) + 1))
             for direction, want in ((0, dl), (1, dr), (2, ds)):
                 _, got = eng.fetch_nn(direction, want_idx=False)
                 assert np.array_equal(got, want), f"{name}: direction {direction}: {int(np.sum(got != want))} of {len(want)} squared distances differ"
