@@ -148,6 +148,7 @@ struct NNOut {
                            //    row always comes along.
 };
 
+// (non-temporal stores here: the brick kernel 90 instead of 70 us, the step 0.194 instead of 0.181 ms -- round 3)
 __device__ __forceinline__ void store_result_rec(const NNOut &o, int qrow, float rx, float ry, float rz, int wrow)
 {
     reinterpret_cast<float4 *>(o.rec)[qrow - o.row_base] = make_float4(rx, ry, rz, __int_as_float(wrow));
