@@ -541,7 +541,7 @@ static BrickShape brick_shape()
 // workgroups per CU (4 x 2176 floats + 3.6 KB of tables = 38.4 KB), the middle one the 4 x 4-row bricks of sharded ranks with
 // three (4 x 3008 floats + 5.4 KB = 53.6 KB -- 3040 floats no longer fit three times; with the large one -- two per CU -- a rank's search took 40 instead of 32 us at
 // 1M points / 8 ranks), the large one is the 64 KB workgroup limit
-constexpr int kPlaneTight = 1728, kPlaneSmall = 2176, kPlaneMid = 3008, kPlaneLarge = 3584;
+constexpr int kPlaneSmall = 2176, kPlaneMid = 3008, kPlaneLarge = 3584;
 
 template <int BY, int BZ, int PL>
 static void launch_plane(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density_q, int force_nt)
@@ -556,8 +556,7 @@ static void launch_plane(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     const size_t lds = (size_t)4 * PL * sizeof(float);
     const size_t lds_wg = lds + (size_t)((BY + 2) * (BZ + 2)) * (kLcsPitch * 2 + 16) + 256;
     const int wgs_per_cu = (int)((size_t)160 * 1024 / lds_wg) > 0 ? (int)((size_t)160 * 1024 / lds_wg) : 1;
-    static const int wave_slots = [] { const char *e = getenv("PCCM_BRICK_SLOTS"); return e ? atoi(e) : 32; }();
-    const int nt_cap = 64 * (wave_slots / (wgs_per_cu > 16 ? 16 : wgs_per_cu));
+    const int nt_cap = 64 * (32 / (wgs_per_cu > 16 ? 16 : wgs_per_cu));
     if (nt > nt_cap) nt = nt_cap;
     if (force_nt > 0) nt = force_nt / 64 * 64;
     if (nt < 128) nt = 128;                             // waves 0 and 1 do the bookkeeping of step 1
@@ -645,11 +644,7 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     if (cap_env > 0) cap = cap_env;
     if (cap < 256) cap = 256;
     // the kernels are compiled for two plane sizes; the budget is the whole plane (it is allocated either way)
-    static const int pl_env = [] { const char *e = getenv("PCCM_BRICK_PL"); return e ? atoi(e) : 0; }();
-    if (pl_env == kPlaneTight) {
-        bp.cap = kPlaneTight - 2;
-        launch_plane<BY, BZ, kPlaneTight>(ctx, jobs, g, self, bp, density_q, force_nt);
-    } else if (cap + 2 <= kPlaneSmall) {
+    if (cap + 2 <= kPlaneSmall) {
         bp.cap = kPlaneSmall - 2;
         launch_plane<BY, BZ, kPlaneSmall>(ctx, jobs, g, self, bp, density_q, force_nt);
     } else if (cap + 2 <= kPlaneMid) {

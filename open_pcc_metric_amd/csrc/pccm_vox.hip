@@ -48,50 +48,49 @@ __constant__ __attribute__((aligned(16))) uint32_t c_vox_rows[kVoxRowsPadded] = 
     0xffff0808, 0xffff0808, 0xffff0808       // padding to whole quadruples: rows nobody can want (row (0, 0) again, at a distance beyond reach)
 };
 
-// The occupied cells of every job in cell order, from the occupancy bitmap the build has written: one workgroup per job, every
-// thread a run of bitmap words (all of them in flight at once: the kernel is two memory round trips and a block scan).
-// (No counter is contended: see k_vox_bricks.  As an extra workgroup of k_vox_bricks' grid, with 256 threads, it was that
-// kernel's long pole: 29 us.)
+// The occupied cells of every job in cell order, from the occupancy bitmap the build has written: kVoxListWGs workgroups per job,
+// each lists the cells of its segment of the bitmap and counts the bits in front of its segment itself (the whole bitmap is a
+// few thousand words: reading it eight times costs less than a second launch or a hand-off between workgroups).
+// (No counter is contended: see k_vox_bricks.)
+constexpr int kVoxListWGs = 8;
 __global__ __launch_bounds__(1024) void k_vox_list(VoxBuild vb)
 {
-    __shared__ uint32_t s_w[16];
-    const VoxBuildJob &J = vb.j[blockIdx.x];
+    __shared__ uint32_t s_w[16], s_before[16];
+    const VoxBuildJob &J = vb.j[blockIdx.y];
     const int64_t ncells = vb.ncells;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t nwords = (ncells + 31) / 32;
     const uint32_t last_mask = (ncells & 31) ? (1u << (ncells & 31)) - 1u : 0xffffffffu;      // (bits beyond the grid are not cells)
-    const int64_t per = (nwords + 1023) / 1024;
-    const int64_t w0 = (int64_t)tid * per, w1 = (w0 + per < nwords) ? w0 + per : nwords;
+    const int64_t seg = (nwords + kVoxListWGs - 1) / kVoxListWGs;
+    const int64_t s0r = (int64_t)blockIdx.x * seg, s0 = s0r < nwords ? s0r : nwords;        // (small grids: the last segments are empty)
+    const int64_t s1 = (s0 + seg < nwords) ? s0 + seg : nwords;
+    // bits in front of the segment
+    uint32_t before = 0u;
+    for (int64_t k = tid; k < s0; k += 1024) before += (uint32_t)__popc(J.occ[k]);
+    // this thread's words of the segment
+    const int64_t per = (seg + 1023) / 1024;
+    const int64_t w0 = s0 + (int64_t)tid * per, w1 = (w0 + per < s1) ? w0 + per : s1;
     uint32_t cnt = 0u;
-    for (int64_t k0 = w0; k0 < w1; k0 += 8) {
-        uint32_t bits[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) bits[u] = (k0 + u < w1) ? J.occ[k0 + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) cnt += (uint32_t)__popc(k0 + u == nwords - 1 ? bits[u] & last_mask : bits[u]);
-    }
+    for (int64_t k = w0; k < w1; ++k) cnt += (uint32_t)__popc(k == nwords - 1 ? J.occ[k] & last_mask : J.occ[k]);
     uint32_t inc = cnt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(inc, off);
         if (lane >= off) inc += o;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
     if (lane == 63) s_w[w] = inc;
+    if (lane == 0) s_before[w] = before;
     __syncthreads();
     uint32_t pos = inc - cnt;
-    for (int k = 0; k < w; ++k) pos += s_w[k];
-    if (tid == 1023) *J.count = pos + cnt;
-    for (int64_t k0 = w0; k0 < w1; k0 += 8) {
-        uint32_t bits[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) bits[u] = (k0 + u < w1) ? J.occ[k0 + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            uint32_t b = k0 + u == nwords - 1 ? bits[u] & last_mask : bits[u];
-            while (b) {
-                J.list[pos++] = (uint32_t)((k0 + u) * 32 + __builtin_ctz(b));
-                b &= b - 1u;
-            }
+    for (int k = 0; k < 16; ++k) pos += s_before[k] + (k < w ? s_w[k] : 0u);
+    if (blockIdx.x == kVoxListWGs - 1 && tid == 1023) *J.count = pos + cnt;
+    for (int64_t k = w0; k < w1; ++k) {
+        uint32_t b = k == nwords - 1 ? J.occ[k] & last_mask : J.occ[k];
+        while (b) {
+            J.list[pos++] = (uint32_t)(k * 32 + __builtin_ctz(b));
+            b &= b - 1u;
         }
     }
 }
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
 {
     __shared__ uint32_t s_cs[40];                 // 9 rows x 4 cell starts of the searched cloud, [36], [37]: the cell's query range
     __shared__ uint32_t s_brick[27 * 16];         // occupancy bricks of the 27 cells (zero: empty / outside)
-    __shared__ uint32_t s_rows[576];              // x-rows of the staged 24^3: bit x + 1 of word [Y * 24 + Z]
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[576];   // x-rows of the staged 24^3: bit x + 1 of word [Z * 24 + Y]
     __shared__ uint32_t s_dup[16];                // SELF: the cell's own voxels that hold more than one point
     const QueryJob &J = jobs.j[blockIdx.y];
     const int lane = threadIdx.x;
@@ -152,17 +151,34 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
     const int gox = (int)g.org[0], goy = (int)g.org[1], goz = (int)g.org[2];
     const uint4 *__restrict__ tab = reinterpret_cast<const uint4 *>(c_vox_rows);
     // one wave per workgroup, one occupied cell of the iterating cloud per turn (a wave's LDS operations execute in order: the
-    // barriers below are scheduling fences only)
+    // barriers below are scheduling fences only).  (Fetching the next turn's list entry and cell starts while this turn
+    // computes was measured: no change -- the turns of 8192 resident waves overlap each other already.)
+    // what a lane does in every turn, worked out once: its two quarter-bricks of the staging (brick b = t / 4 of 27, cell-start
+    // slot r * 4 + k of s_cs) and its three row quads of the transposition
+    int st_cs[2], tr_src[3], tr_dst[3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = lane + 64 * u, b = t >> 2, r = b / 3, k = b - 3 * r;
+        st_cs[u] = t < 27 * 4 ? r * 4 + k : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = lane + 64 * u, Z = t / 6, Yq = t - 6 * Z;                              // 6 quads of Y x 24 Z
+        tr_src[u] = t < 144 ? ((Yq >> 1) + 3 * (Z >> 3)) * 48 + 2 * (Z & 7) + (Yq & 1) : -1;  // brick (r * 3 + 0), word 2 z + (y >> 2)
+        tr_dst[u] = Z * 24 + 4 * Yq;
+    }
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const uint32_t c = J.vlist[it];
         const uint32_t cyz = c / (uint32_t)dimx;
         const int cx = (int)(c - cyz * (uint32_t)dimx), cy = (int)(cyz % (uint32_t)dimy), cz = (int)(cyz / (uint32_t)dimy);
         // ---- 1. cell starts of the 3 x 3 x-runs (cells cx - 1 .. cx + 1, and the end of the last) + the cell's query range -----
         if (lane < 36) {
+            // (a row outside the grid: four zeros = three empty cells; the cell left of the grid takes the start of cell 0 and is
+            // empty too; x = dimx is the end of the row's last cell, anything beyond reads as 0 = an empty cell)
             const int r = lane >> 2, k = lane & 3;
-            const int y = cy + r % 3 - 1, z = cz + r / 3 - 1, x = cx - 1 + k;
+            const int y = cy + r % 3 - 1, z = cz + r / 3 - 1, x = max(cx - 1 + k, 0);
             uint32_t v = 0u;
-            if (y >= 0 && y < dimy && z >= 0 && z < dimz && x >= 0 && x <= dimx) v = cs[((uint32_t)z * dimy + y) * dimx + x];
+            if (y >= 0 && y < dimy && z >= 0 && z < dimz && x <= dimx) v = cs[((uint32_t)z * dimy + y) * dimx + x];
             s_cs[lane] = v;
         } else if (lane < 38) {
             s_cs[lane] = J.qcs[c + (uint32_t)(lane - 36)];
@@ -170,40 +186,41 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
         __builtin_amdgcn_wave_barrier();
         const uint32_t q0 = s_cs[36], nq = s_cs[37] - q0;
         // ---- 2. bricks (a quarter-brick per lane and pass) and the first 64 queries, all in flight together -----------------
-        for (int t = lane; t < 27 * 4; t += 64) {
-            const int b = t >> 2, part = t & 3;
-            const int r = b / 3, k = b - 3 * r;
-            const int y = cy + r % 3 - 1, z = cz + r / 3 - 1, x = cx - 1 + k;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (st_cs[u] < 0) continue;
+            const int part = lane & 3;
+            const uint32_t s = s_cs[st_cs[u]], e = s_cs[st_cs[u] + 1];
             uint4 w = make_uint4(0u, 0u, 0u, 0u), d = w;
-            if (y >= 0 && y < dimy && z >= 0 && z < dimz && x >= 0 && x < dimx) {
-                const uint32_t s = s_cs[r * 4 + k], e = s_cs[r * 4 + k + 1];
-                if (e > s) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(J.vbricks + (size_t)s * 32);
-                    w = src[part];
-                    if (SELF && b == 13) d = src[4 + part];          // (a query's own voxel lies in the cell itself)
-                }
+            const bool own = SELF && (lane + 64 * u) >> 2 == 13;              // (a query's own voxel lies in the cell itself)
+            if (e > s) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(J.vbricks + (size_t)s * 32);
+                w = src[part];
+                if (own) d = src[4 + part];
             }
-            reinterpret_cast<uint4 *>(s_brick)[t] = w;
-            if (SELF && b == 13) reinterpret_cast<uint4 *>(s_dup)[part] = d;
+            reinterpret_cast<uint4 *>(s_brick)[lane + 64 * u] = w;
+            if (own) reinterpret_cast<uint4 *>(s_dup)[part] = d;
         }
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((uint32_t)lane < nq) q = qrecs[q0 + lane];
         __builtin_amdgcn_wave_barrier();
-        // ---- 3. transpose: x-row (Y, Z) of the 24^3 = one byte of each of three bricks (rows lane, lane + 64, ...: Y and Z
-        //         advance by 2 and 16) ---------------------------------------------------------------------------------------
-        {
-            const unsigned char *bb = reinterpret_cast<const unsigned char *>(s_brick);
-            int Y = lane / 24, Z = lane - 24 * Y;
+        // ---- 3. transpose: x-row (Y, Z) of the 24^3 = one byte of each of three bricks.  A word of a brick holds the x-bytes of
+        //         four consecutive y at one z: a lane turns three such words (the three bricks along x) into the four row words
+        //         (Y .. Y + 3, Z) by byte permutes and writes them with one 16-byte store -- rows lie Y-fastest: [Z * 24 + Y] -----
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int b0 = ((Y >> 3) + 3 * (Z >> 3)) * 192 + (Y & 7) + 8 * (Z & 7);
-                // bits 1 .. 24 = voxels x = 0 .. 23; bits 0 and 25 are sentinels ("points" at x = -1 and x = 24: at least 9 away from
-                // every query of the cell, i.e. beyond the 8 this search vouches for): the bit scans below never see an empty word
-                s_rows[lane + 64 * j] = ((uint32_t)bb[b0] << 1) | ((uint32_t)bb[b0 + 64] << 9) | ((uint32_t)bb[b0 + 128] << 17) | 0x2000001u;
-                Y += 2;
-                Z += 16;
-                if (Z >= 24) { Z -= 24; Y += 1; }
+        for (int u = 0; u < 3; ++u) {
+            if (tr_src[u] < 0) continue;
+            const uint32_t b0 = s_brick[tr_src[u]], b1 = s_brick[tr_src[u] + 16], b2 = s_brick[tr_src[u] + 32];
+            uint32_t r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // bits 1 .. 24 = voxels x = 0 .. 23; bits 0 and 25 are sentinels ("points" at x = -1 and x = 24: at least 9 away
+                // from every query of the cell, i.e. beyond the 8 this search vouches for): the bit scans never see an empty word
+                const uint32_t lo = __builtin_amdgcn_perm(b1, b0, 0x0c0c0000u | (uint32_t)i | ((uint32_t)(4 + i) << 8));      // {b0.i, b1.i, 0, 0}
+                const uint32_t all = __builtin_amdgcn_perm(b2, lo, 0x0c000100u | ((uint32_t)(4 + i) << 16));                   // {lo.0, lo.1, b2.i, 0}
+                r[i] = (all << 1) | 0x2000001u;
             }
+            *reinterpret_cast<uint4 *>(&s_rows[tr_dst[u]]) = make_uint4(r[0], r[1], r[2], r[3]);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- 4. queries --------------------------------------------------------------------------------------------------
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
             const bool have = qb + (uint32_t)lane < nq;
             if (qb) q = have ? qrecs[q0 + qb + lane] : q;
             const int lx = have ? (int)q.x - rx0 : 8, ly = have ? (int)q.y - ry0 : 8, lz = have ? (int)q.z - rz0 : 8;   // 8 .. 15
-            const int base = ly * 24 + lz;
+            const int base = lz * 24 + ly;
             const int L = lx + 1;                           // the query's bit in a row word
             const uint32_t below = (1u << L) - 1u;
             uint32_t own = 0xffffffffu;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
                 uint32_t w[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int off = ((int)((ee[u] >> 8) & 0xffu) - 8) * 24 + ((int)(ee[u] & 0xffu) - 8);
+                    const int off = ((int)(ee[u] & 0xffu) - 8) * 24 + ((int)((ee[u] >> 8) & 0xffu) - 8);     // dz * 24 + dy
                     w[u] = s_rows[base + off];
                 }
                 if (SELF && k4 == 0) w[0] &= own;
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
                     // the winning row again: which side, how far
                     const uint32_t e = c_vox_rows[best & 0xffu];
                     const int dy = (int)((e >> 8) & 0xffu) - 8, dz = (int)(e & 0xffu) - 8;
-                    uint32_t w = s_rows[base + dy * 24 + dz];
+                    uint32_t w = s_rows[base + dz * 24 + dy];
                     if (SELF && (best & 0xffu) == 0u) w &= own;
                     const int up = __builtin_ctz(w >> L), dn = __builtin_clz(w & below) + L - 31;
                     const int mx = dn < up ? lx - dn : lx + up;
@@ -270,7 +287,7 @@ int launch_vox_bricks(pccm_ctx *ctx, const VoxBuild &vb, const GridGeom &g)
 {
     dim3 grid((unsigned)((vb.ncells + kVoxTile - 1) / kVoxTile), (unsigned)vb.njobs);
     hipLaunchKernelGGL(k_vox_bricks, grid, dim3(256), 0, ctx->stream, vb, g);
-    hipLaunchKernelGGL(k_vox_list, dim3((unsigned)vb.njobs), dim3(1024), 0, ctx->stream, vb);
+    hipLaunchKernelGGL(k_vox_list, dim3(kVoxListWGs, (unsigned)vb.njobs), dim3(1024), 0, ctx->stream, vb);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
