@@ -893,6 +893,7 @@ static bool vox_feasible(const pccm_ctx *ctx)
     if (off || lattice_off || use_coop(ctx) || ctx->grid.boxed || c0.n <= 0 || c1.n <= 0 || !c0.exact32 || !c1.exact32 || !c0.all_int ||
         !c1.all_int) return false;
     if (!(c0.maxabs < 4194304.0 && c1.maxabs < 4194304.0)) return false;
+    if (c0.n + c1.n > (16ll << 20)) return false;          // brick slots are addressed by record index: 128 B per point reserved (2 GB here)
     double cells = 1.0;
     for (int a = 0; a < 3; ++a) {
         const double lo = fmin(c0.bb_min[a], c1.bb_min[a]), hi = fmax(c0.bb_max[a], c1.bb_max[a]);
