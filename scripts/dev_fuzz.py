@@ -43,6 +43,8 @@ def make(rng, n, kind):
 
 
 KINDS = ["uniform32", "uniform64", "offset64", "lattice", "surface", "clusters", "outliers", "planar", "dups"]
+if os.environ.get("FUZZ_KINDS"):                 # e.g. FUZZ_KINDS=lattice,surface: voxelised pairs (voxel bricks, lattice kernel)
+    KINDS = os.environ["FUZZ_KINDS"].split(",")
 if __name__ != "__main__":
     budget = 0.0
 e = nat.Engine(0) if __name__ == "__main__" else None
@@ -124,7 +126,11 @@ while __name__ == "__main__" and time.time() < t_end:
         e.nn_pair(eng)
         e.nn(nat.DIR_SELF, eng)
         for d, (q, r, skip) in enumerate(((a, b, False), (b, a, False), (a, a, True))):
+            _, d2_only = e.fetch_nn(d, want_idx=False)      # distances first: what a search without rows (voxel bricks) left
             idx, d2 = e.fetch_nn(d)
+            if not np.array_equal(d2_only, d2):
+                fails += 1
+                print(f"MISMATCH (distances-only read) it={it} seed={seed0} dir={d} eng={eng} mode={mode} A={ka}:{na} B={kb}:{nb}", flush=True)
             if skip and na < 2:
                 ok = bool(np.all(idx == -1) and np.all(d2 == 0))
             else:
