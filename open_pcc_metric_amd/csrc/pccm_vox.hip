@@ -150,8 +150,8 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
     const uint32_t *__restrict__ cs = J.cs;
     const int gox = (int)g.org[0], goy = (int)g.org[1], goz = (int)g.org[2];
     const uint4 *__restrict__ tab = reinterpret_cast<const uint4 *>(c_vox_rows);
-    // one wave per workgroup, one occupied cell of the iterating cloud per turn (a wave's LDS operations execute in order: the
-    // barriers below are scheduling fences only).  (Fetching the next turn's list entry and cell starts while this turn
+    // one wave per workgroup, one occupied cell of the iterating cloud per turn (the barriers below cost a single-wave workgroup
+    // next to nothing).  (Fetching the next turn's list entry and cell starts while this turn
     // computes was measured: no change -- the turns of 8192 resident waves overlap each other already.)
     // what a lane does in every turn, worked out once: its two quarter-bricks of the staging (brick b = t / 4 of 27, cell-start
     // slot r * 4 + k of s_cs) and its three row quads of the transposition
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
         } else if (lane < 38) {
             s_cs[lane] = J.qcs[c + (uint32_t)(lane - 36)];
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         const uint32_t q0 = s_cs[36], nq = s_cs[37] - q0;
         // ---- 2. bricks (a quarter-brick per lane and pass) and the first 64 queries, all in flight together -----------------
 #pragma unroll
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
         }
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((uint32_t)lane < nq) q = qrecs[q0 + lane];
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         // ---- 3. transpose: x-row (Y, Z) of the 24^3 = one byte of each of three bricks.  A word of a brick holds the x-bytes of
         //         four consecutive y at one z: a lane turns three such words (the three bricks along x) into the four row words
         //         (Y .. Y + 3, Z) by byte permutes and writes them with one 16-byte store -- rows lie Y-fastest: [Z * 24 + Y] -----
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
             }
             *reinterpret_cast<uint4 *>(&s_rows[tr_dst[u]]) = make_uint4(r[0], r[1], r[2], r[3]);
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         // ---- 4. queries --------------------------------------------------------------------------------------------------
         const int rx0 = gox + 8 * (cx - 1), ry0 = goy + 8 * (cy - 1), rz0 = goz + 8 * (cz - 1);      // voxel (0, 0, 0) of the 24^3
         for (uint32_t qb = 0; qb < nq; qb += 64u) {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();                     // the next cell overwrites the staging
+        __syncthreads();                     // the next cell overwrites the staging
     }
 }
 
