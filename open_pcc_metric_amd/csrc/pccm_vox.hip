@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void k_vox_bricks(VoxBuild vb, GridGeom g)
         const int x = (int)r.x - gox, y = (int)r.y - goy, z = (int)r.z - goz;        // >= 0: the origin is the box's lower corner
         const int64_t lin = ((int64_t)(z >> 3) * dimy + (y >> 3)) * dimx + (x >> 3) - c0;   // 0 .. nc - 1: the records are cell-sorted
         const int v = (x & 7) + 8 * (y & 7) + 64 * (z & 7);
+        if ((uint64_t)lin >= (uint64_t)nc) continue;                      // (cannot happen for cell-sorted integer records: no wild LDS write if it does)
         uint32_t *b = s_b + (int)lin * 32;
         const uint32_t bit = 1u << (v & 31);
         const uint32_t old = atomicOr(&b[v >> 5], bit);
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
         for (uint32_t qb = 0; qb < nq; qb += 64u) {
             const bool have = qb + (uint32_t)lane < nq;
             if (qb) q = have ? qrecs[q0 + qb + lane] : q;
-            const int lx = have ? (int)q.x - rx0 : 8, ly = have ? (int)q.y - ry0 : 8, lz = have ? (int)q.z - rz0 : 8;   // 8 .. 15
+            // 8 .. 15 by construction (clamped all the same: a shift count or an LDS index must never leave its range)
+            const int lx = have ? min(max((int)q.x - rx0, 8), 15) : 8, ly = have ? min(max((int)q.y - ry0, 8), 15) : 8,
+                      lz = have ? min(max((int)q.z - rz0, 8), 15) : 8;
             const int base = lz * 24 + ly;
             const int L = lx + 1;                           // the query's bit in a row word
             const uint32_t below = (1u << L) - 1u;
