@@ -32,38 +32,9 @@
 // writes, second barrier and per-query set-up 26, + cell-start loads 10, + record loads and the scan 35, + fp64
 // epilogue, normal gather and result stores 24 = 104 us.  Reported against HBM as the contract asks.
 // Neighbouring bricks share runs through the XCD's L2 (XCD-aware brick order, as in round 1).
-#include "pccm_grid.h"
+#include "pccm_brick.h"
 
 namespace pccm {
-
-constexpr int kBXMax = 64;
-constexpr int kLcsPitch = kBXMax + 3;                // cell starts per staged run (BX + 2 cells + 1), odd pitch
-typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr float kBigF = 3.0e38f;
-constexpr int kExtra = 21;                           // lanes per run of the staging's second load (3 x 21 <= 64)
-constexpr float kFar = 1.0e18f;                      // coordinates of pad records: d2 ~ 3e36, finite, never the winner
-
-struct BrickParams {
-    int bx;                 // cells per brick along x
-    int nbx, nby, nbz;      // bricks per axis
-    int64_t per_job;        // nbx * nby * nbz
-    uint32_t total;         // bricks of all jobs
-    int cap;                // staged records that fit (< 65536: LDS positions are kept as uint16)
-    unsigned long long *stamps;   // diagnostic build only (PCCM_BRICK_STAMP=1): per-phase wave-cycle sums, else null
-    // the ring-1 stop rule in fp32 (face32): per axis the cell edge and the two face origins, org - h + slack and org + 2 h - slack,
-    // where slack = GridGeom::slack + the worst absolute error of the fp32 evaluation (see launch_brick_query)
-    float h32[3], face_lo[3], face_hi[3];
-};
-
-// Distance from the query coordinate q (cell c of its axis) to the nearer face of the ring-1 cube that has cells behind it --
-// face_bound() of pccm_grid.h in fp32, never larger than it: the faces lie at org + (c - 1) h and org + (c + 2) h
-__device__ __forceinline__ float face32(float q, int c, int dim, float h, float flo, float fhi)
-{
-    const float cf = (float)c;
-    const float lo = q - __builtin_fmaf(cf, h, flo), hi = __builtin_fmaf(cf, h, fhi) - q;
-    const float a = c >= 2 ? lo : INFINITY, b = c <= dim - 3 ? hi : INFINITY;
-    return a < b ? a : b;
-}
 
 // In-kernel stamps (cdna_hip_programming.md section 7): a SEPARATE instantiation of the kernel, selected by
 // PCCM_BRICK_STAMP=1, adds each wave's cycles per phase into bp.stamps; the product kernel (STAMP = false) executes none.
@@ -75,13 +46,6 @@ __device__ __forceinline__ float face32(float q, int c, int dim, float h, float 
             t_last = now_;                                                                   \
         }                                                                                    \
     } while (0)
-
-// min of two non-negative floats (or +inf) by their bit patterns
-__device__ __forceinline__ float umin_f(float a, float b)
-{
-    const uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
-    return __uint_as_float(x < y ? x : y);
-}
 
 // the normal of `row`: one aligned 16-byte word when the cloud's normals are fp32-exact (exact widening), else 24 bytes of fp64
 __device__ __forceinline__ void load_normal(const NNOut &o, int row, double &a, double &b, double &c)
@@ -361,7 +325,10 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         const bool hn = qnext < NQ;                                    // a leftover query (rare: the workgroup is sized to the brick)
         const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
         const int ly = r % BY, lz = r / BY;
-        const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
+        // the x-cell the windows are centred on, in fp32 and clamped to the brick: whatever it is, the windows [cx - 1, cx + 1] are
+        // what is scanned AND what the stop rule below measures its faces from, so a query that sits a rounding away from a cell
+        // border is at worst handed to the tail kernels (the fp64 cell_coord of round 3 cost ten double-precision instructions)
+        const int cx = min(max((int)floorf((q.x - bp.org32x) * bp.invh32x), bx0), bx1 - 1);
         const int cy = by0 + ly, cz = bz0 + lz;
         const int ja = max(cx - 1, 0) - sx0, jb2 = min(cx + 2, dimx) - sx0;
         float best = kBigF, second = kBigF;
@@ -377,40 +344,83 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
                 // the neighbouring cell of the same run (or the run's pad) along -- a real point of the searched cloud outside
                 // the ring-1 cube: if it wins, the stop rule below rejects it; no per-candidate range test is needed
                 // (the loop runs on LDS byte addresses of the x plane: the position of the best candidate is kept as its address)
+                if constexpr (ABL != 0) {
+                // (timing-only ablation builds keep the plain loop: reads, wait, arithmetic)
                 for (uint32_t a = fsb & ~7u, ae = (ABL & 1) ? (fsb < feb ? a + 8u : a) : feb; a < ae; a += 8u) {
-                    // three ds_read_b64 off one address register (left to itself hipcc fuses two of them into a
-                    // ds_read2st64_b64, which the LDS serves at 8 cycles per wave: MI355X_MICROARCH.md, LDS table)
-                    v2f px, py, pz, pr;
-                    if (SELF)
-                        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b64 %2, %4 offset:%6\n\t"
-                                     "ds_read_b64 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(px), "=&v"(py), "=&v"(pz), "=&v"(pr)
-                                     : "v"(a), "n"(4 * PL), "n"(8 * PL), "n"(12 * PL)
-                                     : "memory");
-                    else
-                        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%4\n\tds_read_b64 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(px), "=&v"(py), "=&v"(pz)
-                                     : "v"(a), "n"(4 * PL), "n"(8 * PL)
-                                     : "memory");
-                    // both candidates of the pair at once: v_pk_add / v_pk_mul / v_pk_fma_f32
+                    v2f px, py, pz;
+                    asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%4\n\tds_read_b64 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(px), "=&v"(py), "=&v"(pz)
+                                 : "v"(a), "n"(4 * PL), "n"(8 * PL)
+                                 : "memory");
                     const v2f dx = qxx - px, dy = qyy - py, dz = qzz - pz;
                     v2f dd = dx * dx;
                     dd = __builtin_elementwise_fma(dy, dy, dd);
                     dd = __builtin_elementwise_fma(dz, dz, dd);
-                    float d0 = dd.x, d1 = dd.y;
-                    if (SELF) {
-                        d0 = (__float_as_int(pr.x) == qrow) ? kBigF : d0;
-                        d1 = (__float_as_int(pr.y) == qrow) ? kBigF : d1;
-                    }
-                    // The nearer of the two enters (best, second best, address of the best pair); the farther one is checked
-                    // once, after the scan, for the winning pair only: a pair's farther record can be second best without its
-                    // nearer one being best or second best only as the winner's own partner.  5 VALU per pair (tracking both
-                    // records: 7).  Squared distances are non-negative (or +inf): their order is the order of their bit
-                    // patterns, and v_min_u32 needs no canonicalisation of the loop-carried operand (fminf does)
-                    const float lo = umin_f(d0, d1);
-                    bestpos = __float_as_uint(lo) < __float_as_uint(best) ? a : bestpos;
+                    const float lo = umin_f(dd.x, dd.y);
+                    bestpos = __float_as_uint(lo) < __float_as_uint(best) ? a + 8u : bestpos;
                     second = __builtin_amdgcn_fmed3f(best, second, lo);
                     best = umin_f(best, lo);
+                }
+                } else {
+                    // Software-pipelined: three ds_read_b64 off one address register (left to itself hipcc fuses two of them into
+                    // a ds_read2st64_b64, which the LDS serves at 8 cycles per wave: MI355X_MICROARCH.md, LDS table), and the
+                    // NEXT pair's reads are issued as soon as this pair's coordinates have been consumed by the three
+                    // subtractions, so an LDS round trip runs under the other ten instructions of the pair (round 4: 72.6 ->
+                    // 68.8 us at 1M + 1M points, 580 -> 544 at 8M; the reads and their wait in one statement -- round 3 -- exposed
+                    // a full round trip per pair).  One pair beyond the window is read and dropped: it lies inside the planes
+                    // (the budget leaves four positions behind the last run).  The destination registers are tied ("+v") from the
+                    // first issue to the last wait, so the compiler never copies them while a read is in flight.
+                    uint32_t a = fsb & ~7u;
+                    const uint32_t ae = feb;
+                    v2f px, py, pz, pr;
+                    if (SELF)
+                        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b64 %2, %4 offset:%6\n\tds_read_b64 %3, %4 offset:%7"
+                                     : "=v"(px), "=v"(py), "=v"(pz), "=v"(pr) : "v"(a), "n"(4 * PL), "n"(8 * PL), "n"(12 * PL) : "memory");
+                    else
+                        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%4\n\tds_read_b64 %2, %3 offset:%5"
+                                     : "=v"(px), "=v"(py), "=v"(pz) : "v"(a), "n"(4 * PL), "n"(8 * PL) : "memory");
+                    while (a < ae) {
+                        if (SELF) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(px), "+v"(py), "+v"(pz), "+v"(pr) : : "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(px), "+v"(py), "+v"(pz) : : "memory");
+                        // both candidates of the pair at once: v_pk_add / v_pk_mul / v_pk_fma_f32
+                        v2f dx = qxx - px, dy = qyy - py, dz = qzz - pz;
+                        // (self search: the query's own record is pushed out of the way -- decided HERE, while the row words are
+                        // still the ones just waited for; a use of them behind the next issue makes the compiler park them in a
+                        // copy that it refills from the registers of the reads in flight)
+                        uint32_t k0 = 0u, k1 = 0u;
+                        if (SELF) {
+                            k0 = __float_as_int(pr.x) == qrow ? __float_as_uint(kBigF) : 0u;
+                            k1 = __float_as_int(pr.y) == qrow ? __float_as_uint(kBigF) : 0u;
+                            asm volatile("" : "+v"(k0), "+v"(k1));
+                        }
+                        asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));        // the subtractions stay in front of the next reads
+                        a += 8u;
+                        if (SELF)
+                            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b64 %2, %4 offset:%6\n\tds_read_b64 %3, %4 offset:%7"
+                                         : "+v"(px), "+v"(py), "+v"(pz), "+v"(pr) : "v"(a), "n"(4 * PL), "n"(8 * PL), "n"(12 * PL) : "memory");
+                        else
+                            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%4\n\tds_read_b64 %2, %3 offset:%5"
+                                         : "+v"(px), "+v"(py), "+v"(pz) : "v"(a), "n"(4 * PL), "n"(8 * PL) : "memory");
+                        v2f dd = dx * dx;
+                        dd = __builtin_elementwise_fma(dy, dy, dd);
+                        dd = __builtin_elementwise_fma(dz, dz, dd);
+                        float d0 = dd.x, d1 = dd.y;
+                        if (SELF) {                                              // (bit patterns of non-negative floats order like the floats)
+                            d0 = __uint_as_float(max(__float_as_uint(d0), k0));
+                            d1 = __uint_as_float(max(__float_as_uint(d1), k1));
+                        }
+                        // The nearer of the two enters (best, second best, address of the best pair); the farther one is checked
+                        // once, after the scan, for the winning pair only: a pair's farther record can be second best without its
+                        // nearer one being best or second best only as the winner's own partner.  5 VALU per pair (tracking both
+                        // records: 7).  Squared distances are non-negative (or +inf): their order is the order of their bit
+                        // patterns, and v_min_u32 needs no canonicalisation of the loop-carried operand (fminf does)
+                        const float lo = umin_f(d0, d1);
+                        bestpos = __float_as_uint(lo) < __float_as_uint(best) ? a : bestpos;      // (the pair's address + 8)
+                        second = __builtin_amdgcn_fmed3f(best, second, lo);
+                        best = umin_f(best, lo);
+                    }
+                    if (SELF) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(px), "+v"(py), "+v"(pz), "+v"(pr) : : "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(px), "+v"(py), "+v"(pz) : : "memory");   // the pair beyond the window
                 }
             }
         }
@@ -426,7 +436,7 @@ __device__ __forceinline__ void brick_body(const QueryJobs &jobs, const GridGeom
         } else if (bestpos != 0xffffffffu && best < 1.0e30f && second > thr) {          // (a pad record is no neighbour)
             // the winning pair's two records again: which one has d32 == best (the same arithmetic gives the same bits), and
             // is its partner out of the way?  (both at d32 == best: an exact tie, left to the tail kernels like every near tie)
-            uint32_t f = (bestpos - lds0) >> 2;                     // the pair's first record
+            uint32_t f = (bestpos - 8u - lds0) >> 2;                // the pair's first record (bestpos: its address + 8)
             float partner;
             {
                 const v2f px = *reinterpret_cast<const v2f *>(s_x + f), py = *reinterpret_cast<const v2f *>(s_y + f),
@@ -537,12 +547,6 @@ static BrickShape brick_shape()
     return s;
 }
 
-// plane sizes the kernels are compiled for: the small one holds the bricks of whole clouds at ~1.4 points per cell with four
-// workgroups per CU (4 x 2176 floats + 3.6 KB of tables = 38.4 KB), the middle one the 4 x 4-row bricks of sharded ranks with
-// three (4 x 3008 floats + 5.4 KB = 53.6 KB -- 3040 floats no longer fit three times; with the large one -- two per CU -- a rank's search took 40 instead of 32 us at
-// 1M points / 8 ranks), the large one is the 64 KB workgroup limit
-constexpr int kPlaneSmall = 2176, kPlaneMid = 3008, kPlaneLarge = 3584;
-
 template <int BY, int BZ, int PL>
 static void launch_plane(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, BrickParams bp, double density_q, int force_nt)
 {
@@ -644,14 +648,14 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
     if (cap_env > 0) cap = cap_env;
     if (cap < 256) cap = 256;
     // the kernels are compiled for two plane sizes; the budget is the whole plane (it is allocated either way)
-    if (cap + 2 <= kPlaneSmall) {
-        bp.cap = kPlaneSmall - 2;
+    if (cap + 4 <= kPlaneSmall) {
+        bp.cap = kPlaneSmall - 4;
         launch_plane<BY, BZ, kPlaneSmall>(ctx, jobs, g, self, bp, density_q, force_nt);
-    } else if (cap + 2 <= kPlaneMid) {
-        bp.cap = kPlaneMid - 2;
+    } else if (cap + 4 <= kPlaneMid) {
+        bp.cap = kPlaneMid - 4;
         launch_plane<BY, BZ, kPlaneMid>(ctx, jobs, g, self, bp, density_q, force_nt);
     } else {
-        bp.cap = kPlaneLarge - 2;
+        bp.cap = kPlaneLarge - 4;
         launch_plane<BY, BZ, kPlaneLarge>(ctx, jobs, g, self, bp, density_q, force_nt);
     }
 }
@@ -680,6 +684,10 @@ int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, 
         const double M = fmax(fabs(g.org[a]), fabs(top)) + 2.0 * g.h[a];
         const double slack = g.slack[a] + 8.0 * M * 0x1.0p-24;
         bp.h32[a] = (float)g.h[a];
+        if (a == 0) {
+            bp.org32x = (float)g.org[0];
+            bp.invh32x = (float)g.inv_h[0];
+        }
         bp.face_lo[a] = (float)(g.org[a] - g.h[a] + slack);
         bp.face_hi[a] = (float)(g.org[a] + 2.0 * g.h[a] - slack);
     }

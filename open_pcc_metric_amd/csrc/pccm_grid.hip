@@ -1532,8 +1532,8 @@ int tie_exposure(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, const
 
 void grid_release(pccm_ctx *ctx)
 {
-    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.occ, &ctx->grid.recs, &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum,
-                      &ctx->g_qrecs, &ctx->g_bins, &ctx->g_tmp};
+    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.occ, &ctx->grid.recs, &ctx->grid.vbricks, &ctx->grid.vlist, &ctx->grid.vcount,
+                      &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum, &ctx->g_qrecs, &ctx->g_bins, &ctx->g_tmp};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
