@@ -55,6 +55,20 @@ int grow(void **p, size_t &cap, size_t bytes)
     return PCCM_OK;
 }
 
+// Called behind a wait for the GPU by everything that hands results out: a kernel that met a state it cannot be in has set a
+// bit of the context's error word instead of answering wrongly.  The word is cleared when reported; the results are not usable.
+int check_device_errors(pccm_ctx *ctx)
+{
+    if (!ctx->host_err) return PCCM_OK;
+    const uint32_t e = __atomic_exchange_n(ctx->host_err, 0u, __ATOMIC_RELAXED);
+    if (!e) return PCCM_OK;
+    for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
+    for (auto &s : ctx->slots) s.pending = false;
+    return fail(PCCM_E_STATE, "a search kernel reported an inconsistent state (device error word 0x%x: %s%s): the results of this search were "
+                              "dropped, run it again", e, (e & 1u) ? "the tail launch's wait for its own workgroups ran out; " : "",
+                (e & 2u) ? "a voxel brick contradicts its cell start" : "");
+}
+
 static hipEvent_t take_event(pccm_ctx *ctx)
 {
     if (!ctx->event_pool.empty()) {
@@ -259,7 +273,12 @@ int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
         }
         ctx->own_stream = true;
     }
-    int rc = ensure(ctx, ctx->counters, 16 * sizeof(uint32_t));      // [0..5] per-direction counters, [8..11] rescan tickets
+    int rc = ensure(ctx, ctx->counters, 16 * sizeof(uint32_t));      // [0..5] per-direction counters, [8..11] rescan tickets, [12..15] tail-launch counts
+    if (!rc && hipHostMalloc((void **)&ctx->host_err, 64, hipHostMallocDefault) != hipSuccess) {
+        ctx->host_err = nullptr;
+        rc = fail(PCCM_E_OOM, "hipHostMalloc of the device error word failed");
+    }
+    if (!rc) *ctx->host_err = 0u;
     if (!rc && hipEventCreateWithFlags(&ctx->batch_ev, hipEventDisableTiming) != hipSuccess) rc = fail(PCCM_E_HIP, "hipEventCreate failed");
     if (!rc) rc = ensure(ctx, ctx->stats, 10 * sizeof(unsigned long long));
     if (!rc && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
@@ -285,10 +304,12 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->batch_ev) (void)hipEventDestroy(ctx->batch_ev);
     ctx->batch_ev = nullptr;
+    if (ctx->host_err) (void)hipHostFree(ctx->host_err);
+    ctx->host_err = nullptr;
     for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
     for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
     DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->stats, &ctx->staging,
-                      &ctx->counters, &ctx->color_cols, &ctx->color_idx, &ctx->rescan_part};
+                      &ctx->counters, &ctx->color_cols, &ctx->color_idx, &ctx->rescan_part, &ctx->tail_sync};
     for (DevBuf *b : bufs) free_buf(*b);
     for (auto &g : ctx->graphs) graph_free(g);
     for (auto &s : ctx->slots) {
@@ -862,7 +883,7 @@ int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
     if (ns > 0 && idx) PCCM_HIP(hipMemcpyAsync(idx, res->idx, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (ns > 0 && d2) PCCM_HIP(hipMemcpyAsync(d2, res->d2, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    return PCCM_OK;
+    return check_device_errors(ctx);
 }
 
 static int check_normals(const pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int normal_mode)
@@ -1190,6 +1211,7 @@ int pccm_reduce(pccm_ctx *ctx, int dir, int metric, int normal_mode, double *xve
         if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
     }
     if (s->wait_ev) PCCM_HIP(hipEventSynchronize(s->wait_ev));
+    { int rce = check_device_errors(ctx); if (rce) return rce; }
     s->pending = false;
     const int64_t n = s->n_iter;
     const int64_t xlen = pccm_xvec_len(n);
@@ -1250,6 +1272,7 @@ static int total_from_slot(pccm_ctx *ctx, int dir, int metric, int normal_mode, 
         if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
     }
     if (s->wait_ev) PCCM_HIP(hipEventSynchronize(s->wait_ev));
+    { int rce = check_device_errors(ctx); if (rce) return rce; }
     s->pending = false;
     const int64_t n = s->n_iter, nunits = s->nunits, nblocks = s->nblocks;
     const int64_t nfull = n / kChunk;
@@ -1295,6 +1318,7 @@ static int chunks_from_slot(pccm_ctx *ctx, int dir, int metric, int normal_mode,
         if (!s) return fail(PCCM_E_STATE, "reduction slot lost");
     }
     if (s->wait_ev) PCCM_HIP(hipEventSynchronize(s->wait_ev));
+    { int rce = check_device_errors(ctx); if (rce) return rce; }
     s->pending = false;
     const int64_t n = s->n_iter, nunits = s->nunits, nblocks = s->nblocks;
     const int64_t nfull = n / kChunk, full_rows = nfull * kChunk;
@@ -1621,7 +1645,7 @@ int pccm_sync(pccm_ctx *ctx)
     CHECK_CTX(ctx);
     NOT_CAPTURING(ctx);
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    return PCCM_OK;
+    return check_device_errors(ctx);
 }
 
 int pccm_profile_enable(pccm_ctx *ctx, int on)

@@ -207,6 +207,7 @@ struct QueryJob {
                                          // a cell's first record ...
     const uint32_t *vlist = nullptr;     // ... the ITERATING cloud's occupied cells, in cell order ...
     const uint32_t *vcount = nullptr;    // ... and how many they are
+    const int32_t *vminrow = nullptr;    // voxel-brick grids built with rows: the searched cloud's smallest row per occupied voxel
     const void *srecs;          // searched cloud's records
     const double *s64;          // searched cloud's fp64 rows (emit_result_lookup)
     int64_t row_base;           // first row of the shard (outputs are indexed row - row_base)
@@ -221,7 +222,12 @@ struct QueryJob {
 struct QueryJobs {
     QueryJob j[2];
     int njobs;
+    uint32_t *err = nullptr;    // the context's device error word (pinned host memory; pccm_ctx::host_err), or null
 };
+
+// bits of the device error word: a kernel that meets a state it cannot be in raises one instead of answering wrongly in silence
+constexpr uint32_t kErrTailWait = 1u;      // k_grid_tail: the rescan's wait for the tail workgroups ran out
+constexpr uint32_t kErrVoxState = 2u;      // pccm_vox.hip: a record outside its tile / a query outside its cell
 
 constexpr int kMaxRing = 3;
 
@@ -253,14 +259,17 @@ struct VoxBuildJob {
     const uint32_t *occ;    // the cloud's occupancy bitmap (one bit per cell, written by the build: BuildJob::occ)
     uint32_t *list;         // occupied cells in cell order, [<= records]
     uint32_t *count;        // their number
+    int32_t *minrow = nullptr;   // [records]: smallest row of every occupied voxel, at the cell's first record + the voxel's rank among
+                                 // the brick's set bits (what the search with matched rows gathers), or null: distances-only grid
 };
 struct VoxBuild {
     VoxBuildJob j[2];
     int njobs;
     int64_t ncells;
+    uint32_t *err = nullptr;    // device error word (QueryJobs::err)
 };
 int launch_vox_bricks(pccm_ctx *ctx, const VoxBuild &vb, const GridGeom &g);
-int launch_vox_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self);
+int launch_vox_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, bool rows);
 
 // per-thread search for voxelised (integer-valued) pairs on Rec32 grids (pccm_lattice.hip)
 int launch_lattice_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self);

@@ -22,8 +22,8 @@
 //             fp32-exact clouds: k_brick_query (pccm_brick.hip; LDS brick, fp32 filter, fp64 certification,
 //               fused D2 projection; both directions)
 //             otherwise: k_grid_query_coop (per-wave staging, segment-local fp32)
-//             -> k_grid_finish: few unsettled queries one wave each (wave_tail), many one thread each
-//                (thread_search), rings 1..kMaxRing
+//             -> k_grid_tail, first half: few unsettled queries one wave each (wave_tail), many one thread each
+//                (thread_search), rings 2..kMaxRing; second half of the same launch: the exact rescan below
 //           surfaces and integer lattices (decide_scale, use_coop):
 //             k_grid_query = thread_search for every query, fp64 throughout
 //           -> k2b_fallback (pccm_brute.hip): exact scan of the whole searched cloud for the queries
@@ -34,6 +34,7 @@
 // kernels subtract that slack (g.slack[a]) from every face distance and compare with a strict
 // "<" after shrinking the bound by 2^-30, so a stop is never taken on a rounding coincidence.
 #include "pccm_grid.h"
+#include "pccm_rescan.h"
 
 namespace pccm {
 
@@ -81,6 +82,35 @@ __device__ __forceinline__ void scan_range(const REC *__restrict__ recs, uint32_
     }
 }
 
+// ... the same with the winner's coordinates kept (wave_tail: what the result record or the fused projection needs is then in
+// registers when the search ends)
+struct BestAt {
+    double d, x, y, z;
+    int idx;
+};
+
+template <typename REC, bool SELF, int kBatch>
+__device__ __forceinline__ void scan_range_at(const REC *__restrict__ recs, uint32_t s, uint32_t e, double qx, double qy, double qz, int qrow,
+                                              BestAt &b)
+{
+    for (uint32_t p = s; p < e; p += kBatch) {
+        P3 a[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) a[j] = load_rec(recs, (p + j < e) ? p + j : e - 1);
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const double d = gdist64(qx, qy, qz, a[j].x, a[j].y, a[j].z);
+            bool better = d < b.d || (d == b.d && a[j].row < b.idx);
+            if (SELF) better = better && (a[j].row != qrow);
+            b.d = better ? d : b.d;
+            b.idx = better ? a[j].row : b.idx;
+            b.x = better ? a[j].x : b.x;
+            b.y = better ? a[j].y : b.y;
+            b.z = better ? a[j].z : b.z;
+        }
+    }
+}
+
 // A query kMaxRing rings could not settle (isolated outliers, clouds that overlap only in part) goes on the
 // result's flagged list; k2b_fallback (pccm_brute.hip), launched right after this kernel, finds its exact
 // answer by a scan of the whole searched cloud.  Same filter as there: every possible fp64 winner has
@@ -92,15 +122,18 @@ __device__ __forceinline__ void defer_rescan(const QueryJob &J, int qrow, double
     float tf = thr > 3.0e38 ? 3.0e38f : (float)thr;
     tf = __uint_as_float(__float_as_uint(tf) + 1u);
     const uint32_t pos = atomicAdd(&J.counters[0], 1u);
-    J.flagged[pos] = qrow - (int)J.row_base;
-    J.flag_thr[pos] = tf;
+    // (write-through stores: the rescan may run in the same launch on another XCD -- k_grid_tail -- and reads the list with
+    // agent-scope loads; a release fence per workgroup instead costs a write-back of the XCD's whole L2 each: 57 against 12 us)
+    __hip_atomic_store(&J.flagged[pos], qrow - (int)J.row_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&J.flag_thr[pos], tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- per-thread ring search: the long-tail kernel, and the whole query for surfaces and lattices ----------
 // One query per thread, rings 1..kMaxRing.  from_tail: the queries are the job's tail list and the kernel
 // only runs when that list is too long for wave_tail.
 template <typename REC, bool SELF>
-__device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridGeom &g, int from_tail)
+__device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridGeom &g, int from_tail, uint32_t nblocks,
+                                              uint32_t *retired = nullptr)
 {
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
     for (int jb = 0; jb < jobs.njobs; ++jb) {
@@ -113,7 +146,7 @@ __device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridG
         }
         const uint32_t *__restrict__ cell_start = J.cs;
         const REC *__restrict__ srecs = (const REC *)J.srecs;
-        for (int64_t t0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); t0 < nq; t0 += (int64_t)gridDim.x * 256) {
+        for (int64_t t0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); t0 < nq; t0 += (int64_t)nblocks * 256) {
             const int64_t t = t0 + (threadIdx.x & 63);
             const bool live = t < nq;
             const P3 qa = load_rec(qrecs, (uint32_t)(live ? t : nq - 1));
@@ -169,6 +202,12 @@ __device__ __forceinline__ void thread_search(const QueryJobs &jobs, const GridG
                 emit_result_lookup(J.out, J.s64, qrow, qx, qy, qz, b.idx, b.d);
             }
             if (!done) defer_rescan(J, qrow, b.d);           // still open after kMaxRing rings
+            if (from_tail && retired) {                      // (k_grid_tail: the rescan half of the launch waits for this count)
+                const unsigned long long m = __ballot(live);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((threadIdx.x & 63) == 0 && m)
+                    __hip_atomic_fetch_add(&retired[(jb * 8 + (blockIdx.x & 7u)) * 32], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -358,10 +397,10 @@ __global__ __launch_bounds__(256) void k_grid_query_coop(QueryJobs jobs, GridGeo
 // (the minimum is idempotent).  Long tails (lattice data, where exact ties defeat the fp32
 // certification) go through thread_search instead, which has the parallelism then.
 template <typename REC, bool SELF>
-__device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom &g)
+__device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom &g, uint32_t nblocks, uint32_t *retired)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
+    const uint32_t wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = nblocks * 4u;      // (the launch's tail workgroups, not gridDim.x)
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
     // The first job's tail is handed out to the waves from the front, the second job's from the back (a wave that took an
     // entry of each job in turn walked the chain of dependent round trips -- tail record, cell starts, records, winner --
@@ -394,9 +433,10 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
             const int cx = cell_coord(qx, g.org[0], g.inv_h[0], dimx);
             const int cy = cell_coord(qy, g.org[1], g.inv_h[1], dimy);
             const int cz = cell_coord(qz, g.org[2], g.inv_h[2], dimz);
-            Best b;
+            BestAt b;                                          // (the winner's coordinates travel with it: no look-up behind the search)
             b.d = INFINITY;
             b.idx = 0x7fffffff;
+            b.x = b.y = b.z = 0.0;
             bool done = false;
             // every query on the tail list has been through a ring-1 kernel that could not settle it -- mostly because the
             // stop rule failed, which a second look at ring 1 cannot change: start with the 5 x 5 x 5 cube (it contains
@@ -408,7 +448,7 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
                     if (z >= 0 && z < dimz && y >= 0 && y < dimy) {
                         const uint32_t row = ((uint32_t)z * dimy + y) * dimx;
                         const int x0 = max(cx - r, 0), x1 = min(cx + r, dimx - 1);
-                        scan_range<REC, SELF, 8>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
+                        scan_range_at<REC, SELF, 8>(srecs, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, qrow, b);
                     }
                 }
                 double wm = b.d;
@@ -417,36 +457,100 @@ __device__ __forceinline__ void wave_tail(const QueryJobs &jobs, const GridGeom 
                 int wi = (b.d == wm) ? b.idx : 0x7fffffff;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) wi = min(wi, __shfl_xor(wi, off));
+                // a lane that holds the winner hands its coordinates to everybody (rows are unique per record: one such lane)
+                const unsigned long long holds = __ballot(b.d == wm && b.idx == wi);
+                const int src = holds ? __ffsll((long long)holds) - 1 : 0;
+                b.x = __shfl(b.x, src);
+                b.y = __shfl(b.y, src);
+                b.z = __shfl(b.z, src);
                 b.d = wm;
                 b.idx = wi;
                 done = settled_by(face_bound(g, qx, qy, qz, cx, cy, cz, r), b.d);
             }
-            if (!done) {                                     // wave-uniform
-                if (lane == 0) defer_rescan(J, qrow, b.d);
-                continue;
-            }
             if (lane == 0) {
-                if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }
-                emit_result_lookup(J.out, J.s64, qrow, qx, qy, qz, b.idx, b.d);
+                if (!done) {                                 // (wave-uniform)
+                    defer_rescan(J, qrow, b.d);
+                } else {
+                    if (b.idx == 0x7fffffff) { b.idx = -1; b.d = 0.0; }
+                    emit_result(J.out, qrow, qx, qy, qz, b.idx, b.d, b.x, b.y, b.z);
+                }
+                // retired: the rescan half of the launch may count on this entry's stores
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&retired[(jb * 8 + (blockIdx.x & 7u)) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
 }
 
-// one launch finishes whatever the ring-1 kernel left open: short tails wave-per-query, long tails
-// thread-per-query (each checks the tail length on the device and does nothing when it is not its case)
+// ONE launch finishes whatever the ring-1 kernel left open (round 4; rounds 1-3: two launches, 11.8 + 6.3 us at 1M + 1M points of
+// which the second found its list empty):
+//   workgroups [0, n_tail): short tails wave-per-query, long tails thread-per-query (each checks the tail length on the device
+//     and does nothing when it is not its case); what three rings cannot settle goes on the flagged list (write-through stores).
+//     A wave that has retired tail entries -- result or flagged entry stored and drained -- adds their number to its XCD's shard
+//     of the job's count (one add per retired query: ~600 per launch at 1M + 1M points, spread over eight lines; a count of
+//     finished WORKGROUPS on one word cost 6-12 us of serialised atomics for 512-1024 workgroups);
+//   workgroups [n_tail, n_tail + njobs * n_rescan): the exact rescan of the flagged lists (pccm_rescan.h) -- they wait until
+//     their job's tail list (complete since the previous launch) is retired entirely (one lane polls, with s_sleep) and run
+//     k2b_fallback's body on a flagged list that is complete by then, reading it with agent-scope loads.
+// The wait always ends: the tail workgroups never wait for anybody, and the waiting ones are too few (<= 256 workgroups of 256
+// threads) to keep them off the GPU whatever the dispatch order; should the poll still run out (seconds), the workgroup raises
+// the context's device error word (host memory: the next call that hands results out fails with PCCM_E_STATE) instead of spinning on.
+struct TailSync {
+    uint32_t *retired;       // [2 jobs][8 shards] tail entries retired (settled or flagged), one 128-byte line per shard
+    uint32_t *ticket;        // rescan workgroups that are through (the last one rearms everything)
+    uint32_t *host_err;      // the context's device error word (pinned host memory), or null
+    uint32_t n_tail, n_rescan;
+    uint32_t delay, nap;     // the poll: s_sleep(127) units before the first look, s_sleep(16) units between looks
+};
+constexpr int kTailShardWords = 32;     // words between two shards of TailSync::retired
+
 template <typename REC, bool SELF>
-__global__ __launch_bounds__(256) void k_grid_finish(QueryJobs jobs, GridGeom g)
+__global__ __launch_bounds__(256) void k_grid_tail(QueryJobs jobs, GridGeom g, RescanJobs rjobs, TailSync ts)
 {
-    wave_tail<REC, SELF>(jobs, g);
-    thread_search<REC, SELF>(jobs, g, 1);
+    if (blockIdx.x < ts.n_tail) {
+        wave_tail<REC, SELF>(jobs, g, ts.n_tail, ts.retired);
+        thread_search<REC, SELF>(jobs, g, 1, ts.n_tail, ts.retired);
+        return;
+    }
+    const uint32_t rb = blockIdx.x - ts.n_tail, jb = rb / ts.n_rescan;
+    __shared__ uint32_t s_ok;
+    if (threadIdx.x == 0) {
+        // this job's tail list is complete (the ring-1 kernel of the previous launch wrote it): wait until all of it is retired
+        const uint32_t want = __hip_atomic_load(&jobs.j[jb].counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t ok = 0u;
+        for (uint32_t k = 0; k < ts.delay; ++k) __builtin_amdgcn_s_sleep(127);
+        for (uint32_t spin = 0; spin < (1u << 21); ++spin) {
+            uint32_t got = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                got += __hip_atomic_load(&ts.retired[(jb * 8 + k) * kTailShardWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got >= want) {
+                ok = 1u;
+                break;
+            }
+            for (uint32_t k = 0; k < ts.nap; ++k) __builtin_amdgcn_s_sleep(16);
+        }
+        if (!ok && ts.host_err) atomicOr(ts.host_err, kErrTailWait);
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (s_ok) rescan_body<SELF>(rjobs.j[jb], rb % ts.n_rescan, ts.n_rescan);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the last rescan workgroup through rearms the counts for the next launch (every tail entry has been retired by then)
+        const uint32_t t = __hip_atomic_fetch_add(ts.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - ts.n_tail - 1u) {
+            for (int k = 0; k < 16; ++k) __hip_atomic_store(&ts.retired[k * kTailShardWords], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ts.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // the whole query by the per-thread search (surfaces, lattices; PCCM_GRID_COOP=0)
 template <typename REC, bool SELF>
 __global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g)
 {
-    thread_search<REC, SELF>(jobs, g, 0);
+    thread_search<REC, SELF>(jobs, g, 0, gridDim.x);
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -917,19 +1021,27 @@ struct ShardSort {
 };
 
 static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, uint32_t *zero = nullptr, int nzero = 0, bool *rebuilt = nullptr,
-                       ShardSort *shard = nullptr, bool want_vox = false)
+                       ShardSort *shard = nullptr, int want_vox = 0)     // want_vox: 1 voxel bricks, 2 ... with the rows' table
 {
     if (rebuilt) *rebuilt = false;
     Grid &gr = ctx->grid;
     const uint64_t key = ctx->cloud[0].version * 1000003ull + ctx->cloud[1].version + 1;
     const bool rec32 = !need64 && pair_rec32(ctx);
+    // (the geometry decisions first: which kernel family serves the pair -- Grid::coop, Grid::boxed -- is part of what makes the
+    // voxel bricks feasible; cached per pair)
+    if (ctx->cloud[0].n > 0 || ctx->cloud[1].n > 0) {
+        const int rcd = decide_scale(ctx, key);
+        if (rcd) return rcd;
+    }
     const bool vox = want_vox && rec32 && !shard && vox_feasible(ctx);
+    // a pair that has been asked for matched rows once keeps the rows' table in every later build (a report that alternates
+    // distance-only and row requests would otherwise rebuild the grid at every switch)
+    if (vox && want_vox >= 2) gr.vox_rows_pair = key;
+    const bool vox_rows = vox && (want_vox >= 2 || gr.vox_rows_pair == key);
     const bool same = gr.key == key && gr.n[0] == ctx->cloud[0].n && gr.n[1] == ctx->cloud[1].n && gr.recs.p && gr.rec32 == rec32 &&
-                      gr.vox == vox && (!rec32 || gr.lattice == lattice_pair(ctx, geom_of(gr), rec32));
+                      gr.vox == vox && (!vox_rows || gr.vox_rows) && (!rec32 || gr.lattice == lattice_pair(ctx, geom_of(gr), rec32));
     if (same && (gr.built & need_mask) == need_mask) return PCCM_OK;
     if (same) need_mask |= gr.built;                   // keep what is there, add what is missing
-    int rc0 = decide_scale(ctx, key);
-    if (rc0) return rc0;
     ProfScope ps(ctx, PCCM_K_GRID_BUILD);
     GridGeom g;
     int64_t ncells;
@@ -940,6 +1052,7 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
         if ((rc = ensure(ctx, gr.vbricks, (size_t)(n0 + n1) * 32 * sizeof(uint32_t)))) return rc;
         if ((rc = ensure(ctx, gr.vlist, (size_t)(n0 + n1) * sizeof(uint32_t)))) return rc;
         if ((rc = ensure(ctx, gr.vcount, 2 * sizeof(uint32_t)))) return rc;
+        if (vox_rows && (rc = ensure(ctx, gr.vminrow, (size_t)(n0 + n1) * sizeof(int32_t)))) return rc;
     }
     if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;   // either layout fits
@@ -980,11 +1093,13 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
         VoxBuild vb;
         vb.njobs = 0;
         vb.ncells = ncells;
+        vb.err = ctx->host_err;
         for (int k = 0; k < 2; ++k) {
             if (!(need_mask & (1 << k))) continue;
             const size_t r0 = (size_t)(k ? n0 : 0);
             vb.j[vb.njobs++] = {cs + (size_t)k * (ncells + 1), (const char *)gr.recs.p + r0 * rsz, (uint32_t *)gr.vbricks.p + r0 * 32,
-                                (const uint32_t *)gr.occ.p + (size_t)k * occ_words, (uint32_t *)gr.vlist.p + r0, (uint32_t *)gr.vcount.p + k};
+                                (const uint32_t *)gr.occ.p + (size_t)k * occ_words, (uint32_t *)gr.vlist.p + r0, (uint32_t *)gr.vcount.p + k,
+                                vox_rows ? (int32_t *)gr.vminrow.p + r0 : nullptr};
         }
         if (vb.njobs == 1) vb.j[1] = vb.j[0];
         if (vb.njobs > 0 && (rc = launch_vox_bricks(ctx, vb, g))) return rc;
@@ -1003,6 +1118,7 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
     gr.rec32 = rec32;
     gr.lattice = lattice;
     gr.vox = vox;
+    gr.vox_rows = vox_rows;
     gr.built = need_mask;
     return PCCM_OK;
 }
@@ -1114,15 +1230,52 @@ static int fused_mode(const pccm_ctx *ctx, int dir, const Cloud &it, const Cloud
 }
 
 template <typename REC>
-static void launch_queries(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, bool per_thread, dim3 grid)
+static void launch_queries(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, dim3 grid)
 {
-    if (per_thread) {
-        if (self) hipLaunchKernelGGL((k_grid_query<REC, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-        else hipLaunchKernelGGL((k_grid_query<REC, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-    } else {
-        if (self) hipLaunchKernelGGL((k_grid_finish<REC, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-        else hipLaunchKernelGGL((k_grid_finish<REC, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    if (self) hipLaunchKernelGGL((k_grid_query<REC, true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+    else hipLaunchKernelGGL((k_grid_query<REC, false>), grid, dim3(256), 0, ctx->stream, jobs, g);
+}
+
+// the one tail launch behind a ring-1 kernel: rings 2..3 for its tail lists, then the exact rescan of what is left (k_grid_tail)
+static int launch_tail(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, bool rec32, int64_t nqmax, const Cloud *const *its,
+                       const Cloud *const *ses, NNResult *const *ress)
+{
+    ProfScope pf(ctx, PCCM_K_GRID_FINISH);
+    RescanJobs rj;
+    int rc = rescan_jobs(ctx, jobs.njobs, its, ses, ress, self, &rj);
+    if (rc) return rc;
+    // tails are short (grid-stride loops inside): two waves per SIMD of half the chip are plenty; the rescan's workgroups are few
+    // enough never to keep the tail's off the GPU (see k_grid_tail) and enough to split a cloud finely
+    const int64_t qblocks = (nqmax + 255) / 256;
+    TailSync ts;
+    ts.n_tail = (uint32_t)(qblocks < 1024 ? qblocks : 1024);
+    ts.n_rescan = (uint32_t)(nqmax < 64 ? nqmax : 64);
+    if ((rc = ensure(ctx, ctx->tail_sync, (size_t)2 * (16 * kTailShardWords + 32) * sizeof(uint32_t)))) return rc;
+    if (!ctx->tail_sync_clean) {                           // (first use: the kernels rearm the counts themselves afterwards)
+        if (ctx->capturing) {
+            ctx->capture_failed = true;
+            return fail(PCCM_E_STATE, "run pccm_nn once before graph capture");
+        }
+        PCCM_HIP(hipMemsetAsync(ctx->tail_sync.p, 0, ctx->tail_sync.bytes, ctx->stream));
+        ctx->tail_sync_clean = true;
     }
+    ts.retired = (uint32_t *)ctx->tail_sync.p + (self ? 16 * kTailShardWords + 32 : 0);
+    ts.ticket = ts.retired + 16 * kTailShardWords;
+    ts.host_err = ctx->host_err;
+    // the pollers keep off the lines the tail waves add to for the first ~7 us (no tail is retired earlier) and look every ~0.9 us
+    // afterwards: 64 + 64 pollers that start at once and look every 0.4 us cost the tail waves 6 us (21.8 against 15.5 us)
+    ts.delay = 2;
+    ts.nap = 2;
+    dim3 grid(ts.n_tail + ts.n_rescan * (uint32_t)jobs.njobs);
+    if (rec32) {
+        if (self) hipLaunchKernelGGL((k_grid_tail<Rec32, true>), grid, dim3(256), 0, ctx->stream, jobs, g, rj, ts);
+        else hipLaunchKernelGGL((k_grid_tail<Rec32, false>), grid, dim3(256), 0, ctx->stream, jobs, g, rj, ts);
+    } else {
+        if (self) hipLaunchKernelGGL((k_grid_tail<GridRec, true>), grid, dim3(256), 0, ctx->stream, jobs, g, rj, ts);
+        else hipLaunchKernelGGL((k_grid_tail<GridRec, false>), grid, dim3(256), 0, ctx->stream, jobs, g, rj, ts);
+    }
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
 }
 
 // Exact 1-NN for `ndirs` directions (LEFT and RIGHT fused into the same launches when both are asked for).
@@ -1170,13 +1323,18 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
     // Distances only?  Then a voxelised pair is searched through its voxel bricks (pccm_vox.hip): nobody has asked for the matched
     // rows (pccm_nn_want_idx off, no repeat of a search for them) and no projection is to be fused (an exact tie decides whose
     // error vector is projected).  Whole clouds only.
-    bool want_vox = !ctx->want_idx && !force_idx && nsh == 0;
+    // matched rows wanted (pccm_nn_want_idx, a repeat of a search for them, a projection to fuse: an exact tie decides whose error
+    // vector is projected)?  Then the bricks come with the rows' table and the search enumerates the equidistant voxels; the self
+    // search with rows (nobody in the metric DAG asks for it) takes the lattice kernel
+    int want_vox = nsh == 0 ? 1 : 0;
     for (int d = 0; d < ndirs && want_vox; ++d) {
         const int dir = dirs[d];
         const NNResult &res = ctx->nn[dir];
         if (res.end <= res.begin) continue;
         const Cloud &it = ctx->cloud[dir == PCCM_DIR_RIGHT ? 1 : 0], &se = ctx->cloud[dir == PCCM_DIR_LEFT ? 1 : 0];
-        if (fused_mode(ctx, dir, it, se) >= 0) want_vox = false;
+        const bool rows = ctx->want_idx || force_idx || fused_mode(ctx, dir, it, se) >= 0;
+        if (rows && dir == PCCM_DIR_SELF) want_vox = 0;
+        else if (rows) want_vox = 2;
     }
     if ((rc = ensure_grid(ctx, false, need, side_by_side ? (uint32_t *)ctx->counters.p + 2 * dlo : nullptr, 2 * ndirs, &rebuilt,
                           ride_dir >= 0 ? &ride : nullptr, want_vox))) return rc;
@@ -1189,6 +1347,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
     QueryJobs normal, selfj;
     normal.njobs = 0;
     selfj.njobs = 0;
+    normal.err = selfj.err = ctx->host_err;
     int shard_dirs[3], nshard = 0, job_of_dir[3] = {-1, -1, -1};
     int normal_dirs[2] = {0, 0}, self_dirs[2] = {0, 0};
     int64_t shard_off[3], shard_total = 0;
@@ -1232,12 +1391,14 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
             J.vbricks = (const uint32_t *)gr.vbricks.p + (size_t)(si ? gr.n[0] : 0) * 32;
             J.vlist = (const uint32_t *)gr.vlist.p + (size_t)(ii ? gr.n[0] : 0);
             J.vcount = (const uint32_t *)gr.vcount.p + ii;
+            J.vminrow = gr.vox_rows ? (const int32_t *)gr.vminrow.p + (size_t)(si ? gr.n[0] : 0) : nullptr;
         }
         J.srecs = recs_all + (size_t)(si ? gr.n[0] : 0) * rsz;
         J.s64 = se.xyz64;
         J.row_base = res.begin;
         J.slack32 = exact ? 0.0 : maxabs * 0x1.0p-20;
-        const int fm = fused_mode(ctx, dir, it, se);
+        int fm = fused_mode(ctx, dir, it, se);
+        if (gr.vox && fm == PCCM_NORMAL_NEIGHBOUR) fm = -1;    // matched records carry no projection: the point kernel forms it from the rows
         res.rec_stride = (ctx->want_idx || force_idx) ? 4 : 2;
         // fp32-exact pairs, and no neighbour-indexed projection to fuse: the searches leave the matched record itself (16 bytes,
         // one store) and the reductions form distance and row-indexed projection from rows and normals they read in row order
@@ -1246,7 +1407,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         const bool defer = gr.vox || (!defer_off && gr.rec32 && fm != PCCM_NORMAL_NEIGHBOUR);
         if (defer) res.rec_stride = 2;
         res.rec_layout = defer ? 1 : 0;
-        res.no_rows = gr.vox;
+        res.no_rows = gr.vox && !(gr.vox_rows && want_vox == 2);
         J.out.rec = (double *)res.rec.p;
         J.out.stride = res.rec_stride;
         J.out.nrm = fm >= 0 ? se.nrm64 : nullptr;
@@ -1320,50 +1481,41 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
             nqmax = jobs.j[k].nq > nqmax ? jobs.j[k].nq : nqmax;
         }
         const int64_t qblocks = (nqmax + 255) / 256;
+        const Cloud *its[2], *ses[2];
+        NNResult *ress[2];
+        const int *pd = self ? self_dirs : normal_dirs;
+        for (int k = 0; k < jobs.njobs; ++k) {
+            its[k] = &ctx->cloud[pd[k] == PCCM_DIR_RIGHT ? 1 : 0];
+            ses[k] = &ctx->cloud[pd[k] == PCCM_DIR_LEFT ? 1 : 0];
+            ress[k] = &ctx->nn[pd[k]];
+        }
+        bool tail_launch = true;                 // a ring-1 kernel ran: its tails and the exact rescan share one launch
         if (gr.vox) {
-            {
-                ProfScope ps(ctx, PCCM_K_GRID_QUERY);
-                if ((rc = launch_vox_query(ctx, jobs, g, self))) return rc;
-            }
-            ProfScope pf(ctx, PCCM_K_GRID_FINISH);             // queries with nothing within 8 voxels: the general search
-            dim3 tgrid((unsigned)(qblocks < 1024 ? qblocks : 1024));
-            launch_queries<Rec32>(ctx, jobs, g, self, false, tgrid);
+            ProfScope ps(ctx, PCCM_K_GRID_QUERY);
+            if ((rc = launch_vox_query(ctx, jobs, g, self, gr.vox_rows && want_vox == 2))) return rc;      // (queries with nothing within 8 voxels: the general search)
         } else if (use_coop(ctx)) {
-            {
-                ProfScope ps(ctx, PCCM_K_GRID_QUERY);
-                if (gr.rec32) {
-                    if ((rc = launch_brick_query(ctx, jobs, g, self))) return rc;
-                } else {
-                    dim3 grid((unsigned)((chunks + 3) / 4));
-                    if (self) hipLaunchKernelGGL((k_grid_query_coop<true>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                    else hipLaunchKernelGGL((k_grid_query_coop<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
-                }
+            ProfScope ps(ctx, PCCM_K_GRID_QUERY);
+            if (gr.rec32) {
+                if ((rc = launch_brick_query(ctx, jobs, g, self))) return rc;
+            } else {
+                dim3 grid((unsigned)((chunks + 3) / 4));
+                if (self) hipLaunchKernelGGL((k_grid_query_coop<true>), grid, dim3(256), 0, ctx->stream, jobs, g);
+                else hipLaunchKernelGGL((k_grid_query_coop<false>), grid, dim3(256), 0, ctx->stream, jobs, g);
             }
-            ProfScope pf(ctx, PCCM_K_GRID_FINISH);
-            // tails are short (grid-stride loops inside): a few waves per CU are plenty
-            dim3 tgrid((unsigned)(qblocks < 1024 ? qblocks : 1024));
-            if (gr.rec32) launch_queries<Rec32>(ctx, jobs, g, self, false, tgrid);
-            else launch_queries<GridRec>(ctx, jobs, g, self, false, tgrid);
         } else {
             dim3 grid((unsigned)qblocks);
             ProfScope ps(ctx, PCCM_K_GRID_QUERY);
             if (gr.lattice) {                                // voxelised pair: pccm_lattice.hip
                 if ((rc = launch_lattice_query(ctx, jobs, g, self))) return rc;
-            } else if (gr.rec32) launch_queries<Rec32>(ctx, jobs, g, self, true, grid);
-            else launch_queries<GridRec>(ctx, jobs, g, self, true, grid);
+            } else if (gr.rec32) launch_queries<Rec32>(ctx, jobs, g, self, grid);
+            else launch_queries<GridRec>(ctx, jobs, g, self, grid);
+            tail_launch = false;                 // the per-thread kernels walk all three rings themselves
         }
         PCCM_HIP(hipGetLastError());
-        {
-            // whatever the rings could not settle: exact rescan, list lengths read on the device (an empty list is an
-            // early exit)
-            const Cloud *its[2], *ses[2];
-            NNResult *ress[2];
-            const int *pd = self ? self_dirs : normal_dirs;
-            for (int k = 0; k < jobs.njobs; ++k) {
-                its[k] = &ctx->cloud[pd[k] == PCCM_DIR_RIGHT ? 1 : 0];
-                ses[k] = &ctx->cloud[pd[k] == PCCM_DIR_LEFT ? 1 : 0];
-                ress[k] = &ctx->nn[pd[k]];
-            }
+        if (tail_launch) {
+            if ((rc = launch_tail(ctx, jobs, g, self, gr.rec32, nqmax, its, ses, ress))) return rc;
+        } else {
+            // whatever the rings could not settle: exact rescan, list lengths read on the device (an empty list is an early exit)
             if ((rc = launch_fallback(ctx, jobs.njobs, its, ses, ress, self))) return rc;
         }
     }
@@ -1532,7 +1684,7 @@ int tie_exposure(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, const
 
 void grid_release(pccm_ctx *ctx)
 {
-    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.occ, &ctx->grid.recs, &ctx->grid.vbricks, &ctx->grid.vlist, &ctx->grid.vcount,
+    DevBuf *bufs[] = {&ctx->grid.cell_start, &ctx->grid.occ, &ctx->grid.recs, &ctx->grid.vbricks, &ctx->grid.vlist, &ctx->grid.vcount, &ctx->grid.vminrow,
                       &ctx->g_cell_of, &ctx->g_rank, &ctx->g_hist, &ctx->g_blocksum, &ctx->g_qrecs, &ctx->g_bins, &ctx->g_tmp};
     for (DevBuf *b : bufs) {
         if (b->p) (void)hipFree(b->p);

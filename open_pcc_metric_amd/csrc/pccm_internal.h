@@ -136,6 +136,10 @@ struct Grid {                    // one geometry, both clouds (grid engine)
     DevBuf vbricks;                // uint32 [n[0] + n[1]][32]: occupancy + duplicate brick at the index of a cell's first record
     DevBuf vlist;                  // uint32 [n[0] + n[1]]: occupied cells of cloud 0, then (from n[0]) of cloud 1
     DevBuf vcount;                 // uint32 [2]
+    bool vox_rows = false;         // ... and the bricks come with the rows' table below (searches that return the matched row)
+    uint64_t vox_rows_pair = 0;    // pair key for which matched rows have been asked for (its later builds keep the table)
+    DevBuf vminrow;                // int32 [n[0] + n[1]]: smallest row of every occupied voxel, at the cell's first record + the voxel's
+                                   // rank among the set bits of the cell's brick
 };
 
 struct ReduceSlot {            // one enqueued reduction (pccm_reduce_prefetch / pccm_reduce)
@@ -192,11 +196,17 @@ struct pccm_ctx {
     // scratch
     pccm::DevBuf part_b1, part_g, part_b2, val, stats, staging, counters;
     pccm::DevBuf rescan_part;             // k2b_fallback's split regime: partial minima per (query, workgroup)
+    pccm::DevBuf tail_sync;               // k_grid_tail: retired-entry counts + ticket, for the normal and the self pass
+    bool tail_sync_clean = false;
     pccm::DevBuf color_cols, color_idx;   // colour pass: squares as three columns / caller-supplied neighbour rows
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
     pccm::DevBuf g_bins, g_tmp;            // grid build: per-tile bin histogram + scan state; bin-partitioned records
     hipEvent_t batch_ev = nullptr;   // recorded once behind every batch of reductions (ReduceSlot::wait_ev)
+    // device error word (pinned host memory the kernels can write): a kernel that meets a state it cannot be in -- a cell start
+    // that contradicts the occupancy brick (pccm_vox.hip), a tail wait that ran out (k_grid_tail) -- sets a bit instead of
+    // answering wrongly in silence; every call that hands results to the caller checks it behind its wait (check_device_errors)
+    uint32_t *host_err = nullptr;
     bool bins_clean = false;   // the build's bin cursors (head of g_bins) are zero on the stream
     bool colsum_configured = false;        // k_color_colsum's dynamic-LDS opt-in was set on this context's device
     int want_idx = 1;                      // pccm_nn_want_idx: searches store the matched row with every result
@@ -258,6 +268,7 @@ int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the cu
 int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)
 int estimate_normals(pccm_ctx *ctx, int which, int k);
 int tie_exposure(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, const NNResult &res, int normal_mode, double out[8]);
+int check_device_errors(pccm_ctx *ctx);           // PCCM_E_STATE when a kernel raised the context's device error word
 // exact rescan of the flagged queries of njobs <= 2 results (k2b_fallback)
 int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Cloud *const *ses, NNResult *const *ress, bool self);
 
@@ -327,6 +338,9 @@ struct UnitJobs {
     int64_t uoff[9];            // prefix sums of 8 * nunits, each rounded up to a multiple of 256
     int64_t toff[9];            // prefix sums of tail_n
 };
+// the rescan jobs of njobs <= 2 results (scratch allocated), for k2b_fallback or the rescan half of k_grid_tail
+int rescan_jobs(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Cloud *const *ses, NNResult *const *ress, bool self, RescanJobs *out);
+constexpr unsigned kRescanCap = 512;   // most workgroups that ever share one job's list (sizes the split regime's partials)
 int launch_point_jobs(pccm_ctx *ctx, const PointJobs &jobs);
 // result records -> plain columns (q32 / row0: the iterating cloud's rows, for records of layout 1)
 int launch_unpack(pccm_ctx *ctx, const double *rec, int stride, int layout, const float4 *q32, int64_t row0, int64_t ns, int32_t *idx, double *d2);

@@ -1,11 +1,14 @@
-// Voxel-brick search for VOXELISED content on gfx950 when only DISTANCES are asked for (D1 MSE / PSNR / Hausdorff, the
-// intrinsic resolution): both clouds integer-valued (every PCC test sequence: 8i, Owlii, MVUB -- BASELINE.json configs[4]).
+// Voxel-brick search for VOXELISED content on gfx950: both clouds integer-valued (every PCC test sequence: 8i, Owlii, MVUB --
+// BASELINE.json configs[4]).
 //
-// Stands under get_neighbour_cloud(), open_pcc_metric/cloud_pair.py:10-42, for the callers that read nothing but the squared
-// distances of its result (cloud_pair.py:102-106 -> metric.py:213-247, 353-386).  Whoever needs the matched ROW (colour
-// metrics, error vectors, D2 projections: an exact tie decides which neighbour's row / error vector is taken) gets the
-// per-thread lattice search (pccm_lattice.hip) on a grid of its own cell size: the library repeats the search then, as it does
-// for pccm_nn_want_idx (include/pccm.h).
+// Stands under get_neighbour_cloud(), open_pcc_metric/cloud_pair.py:10-42.  Two flavours of one kernel: distances only (round 3:
+// the callers that read nothing but the squared distances, cloud_pair.py:102-106 -> metric.py:213-247, 353-386), and -- round
+// 4 -- with the matched ROW (cloud_pair.py:34-40: colour metrics, error vectors, D2 projections, where an exact tie decides
+// which neighbour's row / error vector is taken): once the nearest distance is known, the voxels at exactly that distance are
+// enumerated in the staged bits and the smallest row among their points wins, the rule of every other kernel of the library.
+// A voxel's smallest row is one gathered word: `minrow`, one entry per occupied voxel of a cell in voxel order, at the cell's
+// first record + the voxel's rank among the brick's set bits (k_vox_bricks).  Only the self search with rows (nobody in the
+// metric DAG asks for it) still takes the per-thread lattice search (pccm_lattice.hip).
 //
 // The pair's grid has cells of exactly 8 x 8 x 8 voxels here (origin on the integer lattice), and every occupied cell of a
 // cloud owns a 512-bit occupancy BRICK (bit x + 8 y + 64 z; k_vox_bricks, one pass over the cell-sorted records) plus a brick of
@@ -21,7 +24,8 @@
 //      the best d2 so far.
 // A best d2 <= 64 is final: every voxel within 8 of a query of the cell lies inside the staged 24^3.  Anything farther (or
 // nothing found) goes to the tail list and through the general kernels (k_grid_finish -> k2b_fallback), like the brick kernel's.
-// Results are matched records {x, y, z of the nearest voxel, row -1} (NNOut::layout 1): the reductions form the distance.
+// Results are matched records {x, y, z of the nearest voxel, its smallest row or -1} (NNOut::layout 1): the reductions form the
+// distance (and the row-indexed projection).
 // Bound: the launch is short and latency-bound (two dependent round trips per wave, thousands of waves in flight); the per-row
 // walk is ~12 VALU instructions.
 #include "pccm_grid.h"
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(1024) void k_vox_list(VoxBuild vb)
 // search to walk is NOT appended here: appends through one device-scope counter -- one per cell, or one per tile -- cost 45 us,
 // returning atomics on one address from eight XCDs serialise at memory.  k_vox_list makes it from the occupancy bitmap.)
 constexpr int kVoxTile = 64;
+constexpr int kVoxMinCap = 4096;                     // records of a tile whose voxel rows are sorted out in LDS at a time
 __global__ __launch_bounds__(256) void k_vox_bricks(VoxBuild vb, GridGeom g)
 {
     __shared__ uint32_t s_b[kVoxTile * 32];
@@ -122,7 +127,10 @@ __global__ __launch_bounds__(256) void k_vox_bricks(VoxBuild vb, GridGeom g)
         const int x = (int)r.x - gox, y = (int)r.y - goy, z = (int)r.z - goz;        // >= 0: the origin is the box's lower corner
         const int64_t lin = ((int64_t)(z >> 3) * dimy + (y >> 3)) * dimx + (x >> 3) - c0;   // 0 .. nc - 1: the records are cell-sorted
         const int v = (x & 7) + 8 * (y & 7) + 64 * (z & 7);
-        if ((uint64_t)lin >= (uint64_t)nc) continue;                      // (cannot happen for cell-sorted integer records: no wild LDS write if it does)
+        if ((uint64_t)lin >= (uint64_t)nc) {                              // cannot happen for cell-sorted integer records: no wild LDS write if
+            if (vb.err) atomicOr(vb.err, kErrVoxState);                   // it does, and the host hears of it (PCCM_E_STATE behind its next wait)
+            continue;
+        }
         uint32_t *b = s_b + (int)lin * 32;
         const uint32_t bit = 1u << (v & 31);
         const uint32_t old = atomicOr(&b[v >> 5], bit);
@@ -134,11 +142,46 @@ __global__ __launch_bounds__(256) void k_vox_bricks(VoxBuild vb, GridGeom g)
         const uint32_t a = s_cs[j];
         if (s_cs[j + 1] > a) J.bricks[(size_t)a * 32 + (k & 31)] = s_b[k];
     }
+    if (!J.minrow) return;                                // (block-uniform: distances-only grids carry no rows)
+    // ---- the smallest row of every occupied voxel, in voxel order: entry [cell's first record + rank of the voxel among the
+    //      brick's set bits] (at most one entry per record: the array is as long as the records).  Set bits in front of every
+    //      word of a cell's brick first, then one LDS atomicMin per record; tiles of more than kVoxMinCap records in pieces.
+    __shared__ uint16_t s_pre[kVoxTile * 16];
+    __shared__ int s_min[kVoxMinCap];
+    if (tid < nc) {
+        uint32_t run = 0u;
+        for (int wv = 0; wv < 16; ++wv) {
+            s_pre[tid * 16 + wv] = (uint16_t)run;
+            run += (uint32_t)__popc(s_b[tid * 32 + wv]);
+        }
+    }
+    for (uint32_t p0 = s; p0 < e; p0 += (uint32_t)kVoxMinCap) {
+        __syncthreads();                                  // (s_pre written / the previous piece copied out)
+        for (int k = tid; k < kVoxMinCap; k += 256) s_min[k] = 0x7fffffff;
+        __syncthreads();
+        for (uint32_t p = s + (uint32_t)tid; p < e; p += 256u) {
+            const float4 r = recs[p];
+            const int x = (int)r.x - gox, y = (int)r.y - goy, z = (int)r.z - goz;
+            const int64_t lin = ((int64_t)(z >> 3) * dimy + (y >> 3)) * dimx + (x >> 3) - c0;
+            if ((uint64_t)lin >= (uint64_t)nc) continue;                      // (reported above)
+            const int v = (x & 7) + 8 * (y & 7) + 64 * (z & 7);
+            const uint32_t rank = (uint32_t)s_pre[(int)lin * 16 + (v >> 5)] + (uint32_t)__popc(s_b[(int)lin * 32 + (v >> 5)] & ((1u << (v & 31)) - 1u));
+            const uint32_t dst = s_cs[(int)lin] + rank;                        // < the cell's end: a rank counts distinct voxels of the cell
+            if (dst >= p0 && dst - p0 < (uint32_t)kVoxMinCap) atomicMin(&s_min[dst - p0], __float_as_int(r.w));
+        }
+        __syncthreads();
+        const uint32_t pe = (e - p0 < (uint32_t)kVoxMinCap) ? e - p0 : (uint32_t)kVoxMinCap;
+        for (uint32_t k = (uint32_t)tid; k < pe; k += 256u) J.minrow[p0 + k] = s_min[k];
+    }
 }
 
-template <bool SELF>
+constexpr int kVoxTies = 8;                         // equidistant nearest voxels a query may have before it is left to the tail kernels
+
+template <bool SELF, bool ROWS>
 __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
 {
+    static_assert(!(SELF && ROWS), "the self search with matched rows takes the lattice kernel");
+    __shared__ uint32_t s_hit[ROWS ? kVoxTies * 64 : 1];   // ROWS: the lanes' equidistant nearest voxels, packed (below)
     __shared__ uint32_t s_cs[40];                 // 9 rows x 4 cell starts of the searched cloud, [36], [37]: the cell's query range
     __shared__ uint32_t s_brick[27 * 16];         // occupancy bricks of the 27 cells (zero: empty / outside)
     __shared__ __attribute__((aligned(16))) uint32_t s_rows[576];   // x-rows of the staged 24^3: bit x + 1 of word [Z * 24 + Y]
@@ -229,9 +272,11 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
         for (uint32_t qb = 0; qb < nq; qb += 64u) {
             const bool have = qb + (uint32_t)lane < nq;
             if (qb) q = have ? qrecs[q0 + qb + lane] : q;
-            // 8 .. 15 by construction (clamped all the same: a shift count or an LDS index must never leave its range)
-            const int lx = have ? min(max((int)q.x - rx0, 8), 15) : 8, ly = have ? min(max((int)q.y - ry0, 8), 15) : 8,
-                      lz = have ? min(max((int)q.z - rz0, 8), 15) : 8;
+            // 8 .. 15 by construction (clamped all the same: a shift count or an LDS index must never leave its range -- and a query
+            // that does lie outside its cell raises the device error word: the host fails the search instead of reporting it)
+            const int ux = (int)q.x - rx0, uy = (int)q.y - ry0, uz = (int)q.z - rz0;
+            if (have && ((((ux | uy | uz) & ~15) != 0) || ((ux & uy & uz & 8) == 0)) && jobs.err) atomicOr(jobs.err, kErrVoxState);
+            const int lx = have ? min(max(ux, 8), 15) : 8, ly = have ? min(max(uy, 8), 15) : 8, lz = have ? min(max(uz, 8), 15) : 8;
             const int base = lz * 24 + ly;
             const int L = lx + 1;                           // the query's bit in a row word
             const uint32_t below = (1u << L) - 1u;
@@ -264,7 +309,72 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
                     best = key < best ? key : best;
                 }
             }
-            if (have) {
+            if (ROWS) {
+                // ---- 5. the matched row: every voxel at exactly the nearest distance, then the smallest row among their points
+                const uint32_t d2 = best >> 8;
+                const bool ok = have && d2 <= 64u;
+                uint32_t cnt = 0u;
+                for (int k4 = 0; k4 < kVoxRowsPadded / 4; ++k4) {
+                    const uint4 e4 = tab[k4];
+                    if (__ballot(ok && d2 >= (e4.x >> 16)) == 0ull) break;     // (rows are sorted by dy^2 + dz^2: nobody reaches further)
+                    const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t r2 = ee[u] >> 16;
+                        if (!(ok && r2 <= d2)) continue;
+                        const uint32_t rem = d2 - r2;
+                        const uint32_t dx = (uint32_t)(__builtin_sqrtf((float)rem) + 0.5f);
+                        if (dx * dx != rem) continue;                             // no voxel of this row lies at exactly d2
+                        const int dz = (int)(ee[u] & 0xffu) - 8, dy = (int)((ee[u] >> 8) & 0xffu) - 8;
+                        const uint32_t w = s_rows[base + dz * 24 + dy];
+                        const int Y = ly + dy, Z = lz + dz;                       // 0 .. 23: |dy|, |dz| <= 8 around 8 .. 15
+                        const int rr = (Y >> 3) + 3 * (Z >> 3);
+#pragma unroll
+                        for (int side = 0; side < 2; ++side) {
+                            if (side == 1 && dx == 0u) continue;
+                            const int X = side == 0 ? lx + (int)dx : lx - (int)dx;  // 0 .. 23 likewise
+                            if (!((w >> (X + 1)) & 1u)) continue;
+                            const int b = rr * 3 + (X >> 3), v = (X & 7) + 8 * (Y & 7) + 64 * (Z & 7);
+                            uint32_t rank = (uint32_t)__popc(s_brick[b * 16 + (v >> 5)] & ((1u << (v & 31)) - 1u));
+                            for (int wv = 0; wv < (v >> 5); ++wv) rank += (uint32_t)__popc(s_brick[b * 16 + wv]);
+                            if (cnt < (uint32_t)kVoxTies) s_hit[cnt * 64u + (uint32_t)lane] = ((uint32_t)b << 18) | (rank << 9) | (uint32_t)v;
+                            ++cnt;
+                        }
+                    }
+                }
+                // the candidates' rows: all gathers in flight together, then the smallest
+                int rows_of[kVoxTies];
+#pragma unroll
+                for (int j = 0; j < kVoxTies; ++j) {
+                    rows_of[j] = 0x7fffffff;
+                    if ((uint32_t)j < cnt && cnt <= (uint32_t)kVoxTies) {
+                        const uint32_t h = s_hit[j * 64 + lane], b = h >> 18, r = b / 3u;
+                        rows_of[j] = J.vminrow[s_cs[r * 4u + (b - 3u * r)] + ((h >> 9) & 0x1ffu)];
+                    }
+                }
+                int wrow = 0x7fffffff;
+                uint32_t wh = 0u;
+#pragma unroll
+                for (int j = 0; j < kVoxTies; ++j)
+                    if (rows_of[j] < wrow) {
+                        wrow = rows_of[j];
+                        wh = s_hit[j * 64 + lane];
+                    }
+                if (have) {
+                    if (ok && cnt >= 1u && cnt <= (uint32_t)kVoxTies && wrow != 0x7fffffff) {
+                        const uint32_t b = wh >> 18, v = wh & 0x1ffu, r = b / 3u;
+                        const int X = 8 * (int)(b - 3u * r) + (int)(v & 7u), Y = 8 * (int)(r % 3u) + (int)((v >> 3) & 7u),
+                                  Z = 8 * (int)(r / 3u) + (int)(v >> 6);
+                        store_result_rec(J.out, __float_as_int(q.w), (float)(rx0 + X), (float)(ry0 + Y), (float)(rz0 + Z), wrow);
+                    } else {
+                        // nothing within 8 voxels, more equidistant neighbours than the list holds, or (cannot happen) a set bit
+                        // without a row: the general kernels decide
+                        if (ok && (cnt == 0u || (cnt <= (uint32_t)kVoxTies && wrow == 0x7fffffff)) && jobs.err) atomicOr(jobs.err, kErrVoxState);
+                        const uint32_t pos = atomicAdd(&J.counters[1], 1u);
+                        reinterpret_cast<float4 *>(J.tail)[pos] = q;
+                    }
+                }
+            } else if (have) {
                 const uint32_t d2 = best >> 8;
                 const int qrow = __float_as_int(q.w);
                 if (d2 <= 64u) {
@@ -295,12 +405,14 @@ int launch_vox_bricks(pccm_ctx *ctx, const VoxBuild &vb, const GridGeom &g)
     return PCCM_OK;
 }
 
-int launch_vox_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self)
+int launch_vox_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self, bool rows)
 {
     // one wave per occupied cell and turn, 32 waves per CU resident: a fixed grid walks the list (its length lives on the device)
     dim3 grid(8192u, (unsigned)jobs.njobs);
-    if (self) hipLaunchKernelGGL((k_vox_query<true>), grid, dim3(64), 0, ctx->stream, jobs, g);
-    else hipLaunchKernelGGL((k_vox_query<false>), grid, dim3(64), 0, ctx->stream, jobs, g);
+    if (self && rows) return fail(PCCM_E_STATE, "the self search with matched rows does not run on voxel bricks");
+    if (self) hipLaunchKernelGGL((k_vox_query<true, false>), grid, dim3(64), 0, ctx->stream, jobs, g);
+    else if (rows) hipLaunchKernelGGL((k_vox_query<false, true>), grid, dim3(64), 0, ctx->stream, jobs, g);
+    else hipLaunchKernelGGL((k_vox_query<false, false>), grid, dim3(64), 0, ctx->stream, jobs, g);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }

@@ -1,12 +1,14 @@
-"""The voxel-brick search (open_pcc_metric_amd/csrc/pccm_vox.hip): voxelised pairs whose callers read distances only
-(cloud_pair.py:102-106 -> metric.py:213-247, 353-386 of the reference).  Against the oracle, bit for bit:
+"""The voxel-brick search (open_pcc_metric_amd/csrc/pccm_vox.hip): voxelised pairs, distances only
+(cloud_pair.py:102-106 -> metric.py:213-247, 353-386 of the reference) or -- round 4 -- with the matched rows
+(cloud_pair.py:34-40).  Against the oracle, bit for bit:
 
 * squared distances of both directions and of the self search (the intrinsic resolution) on content with duplicates
   inside a cloud (the self search's "another point at distance 0"), negative coordinates, points farther than the
   8 voxels the bricks vouch for (the tail kernels take those) and clouds of different sizes;
-* whoever asks for matched rows afterwards (nn indices, error vectors, point-to-plane with neighbour normals) gets the
-  searched-with-rows answer: the library repeats the search on a grid of its usual cell size (include/pccm.h,
-  pccm_nn_want_idx);
+* whoever asks for matched rows (nn indices, error vectors, point-to-plane with neighbour normals, colours) gets them from
+  the same bricks: the voxels at exactly the nearest distance are enumerated and the smallest row among their points wins,
+  the tie rule of every other kernel (include/pccm.h); a pair that was first read for distances only is searched again with
+  the rows' table built;
 * PCCM_VOX=0 (the per-thread lattice search) gives the same numbers: tests/test_gpu_ab_paths.py."""
 import numpy as np
 import pytest
@@ -91,3 +93,81 @@ def test_vox_report_then_d2():
         got2 = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, True))).as_dict()
         for key, val in want2.items():
             assert got2[key] == val, key
+
+
+@pytest.mark.parametrize("name", ["shell_dups_strays", "small_unequal", "holes", "one_cell"])
+def test_vox_rows_match_oracle(name):
+    """Matched rows straight from the voxel-brick search (pccm_nn_want_idx on before the first search): indices, distances and
+    error vectors of both directions equal the oracle's (smallest row among equidistant nearest neighbours)."""
+    a, b = CASES[name]
+    from open_pcc_metric_amd import _native as nat
+    eng = nat.Engine(0)
+    try:
+        eng.set_cloud(0, a)
+        eng.set_cloud(1, b)
+        eng.nn_want_idx(True)
+        for _ in range(2):                                   # first build, then a rebuild behind pccm_drop_caches
+            eng.drop_caches()
+            eng.nn_pair("grid")
+            lo, hi = np.minimum(a.min(0), b.min(0)), np.maximum(a.max(0), b.max(0))
+            assert eng.nn_stats(0)["splits"] == int(np.prod(np.floor((hi - lo) / 8.0) + 1)), "not the voxel-brick grid"
+            for direction, (q, r) in ((0, (a, b)), (1, (b, a))):
+                want_idx, want_d2 = orc.nn(q, r, method="kdtree")
+                idx, d2 = eng.fetch_nn(direction)
+                assert np.array_equal(d2, want_d2)
+                assert np.array_equal(idx, want_idx), f"{name}: direction {direction}: {int(np.sum(idx != want_idx))} rows differ"
+                err = eng.error_vectors(direction)
+                assert np.array_equal(err, q.astype(np.float64) - r.astype(np.float64)[want_idx])
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_vox_same_pair_distances_then_normals_then_d2(use_graph):
+    """ONE pair: a distances-only report through the voxel bricks, then normals arrive (set on the resident clouds) and the
+    point-to-plane rows are asked of the same pair -- row-indexed normals (the reference's D2) on clouds of equal size, eagerly and
+    through a hipGraph replay."""
+    rng = np.random.default_rng(5)
+    a = shell(60_000, 21, (10, 20, -5), 90, dup=0)
+    b = np.ascontiguousarray((a + np.rint(rng.normal(0, 0.6, a.shape))).astype(np.float32))      # same size: row-indexed normals are legal
+    na = rng.standard_normal(a.shape).astype(np.float32)
+    nb = rng.standard_normal(b.shape).astype(np.float32)
+    want1 = orc.OraclePair(a, b, None, None, method="kdtree").report(hausdorff=True, point_to_plane_=False, peak=300.0)
+    want2 = orc.OraclePair(a, b, na, nb, method="kdtree").report(hausdorff=True, point_to_plane_=True, peak=300.0)
+    ca, cb = PointCloud(a), PointCloud(b)
+    with CloudPair(ca, cb, extent=[300.0, 300.0, 300.0], device=0, use_graph=use_graph, estimate_normals=False) as pair:
+        for _ in range(3):
+            pair.recompute()
+            got1 = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, False))[2:]).as_dict()
+            for key in got1:
+                assert got1[key] == want1[key], key
+        # the normals arrive
+        ca.normals, cb.normals = na, nb
+        pair._engine.set_normals(0, na)
+        pair._engine.set_normals(1, nb)
+        pair._update_fusion()
+        for _ in range(3):                                   # eager, capture, replay
+            pair.recompute()
+            got2 = MetricCalculator(pair).calculate(transform_options(CalculateOptions(None, True, True))[2:]).as_dict()
+            for key in got2:
+                assert got2[key] == want2[key], key
+
+
+def test_vox_colours_and_neighbour_normals_stay_on_the_bricks():
+    """The configs[4]-shaped request -- colour metrics and point-to-plane with the neighbour's normal on clouds of different sizes --
+    is served by one voxel-brick grid (no rebuild with other cells), and equals the oracle."""
+    a, b = CASES["shell_dups_strays"]
+    rng = np.random.default_rng(19)
+    na = rng.standard_normal(a.shape).astype(np.float32)
+    nb = rng.standard_normal(b.shape).astype(np.float32)
+    cola, colb = rng.integers(0, 256, a.shape).astype(np.float64) / 255.0, rng.integers(0, 256, b.shape).astype(np.float64) / 255.0
+    o = orc.OraclePair(a, b, na, nb, method="kdtree", normal_index="neighbour")
+    want = o.report(hausdorff=True, point_to_plane_=True, peak=300.0)
+    with CloudPair(PointCloud(a, na, cola), PointCloud(b, nb, colb), extent=[300.0, 300.0, 300.0], device=0, normal_index="neighbour") as pair:
+        got = MetricCalculator(pair).calculate(transform_options(CalculateOptions("ycc", True, True))).as_dict()
+        for key, val in want.items():
+            assert got[key] == val, key
+        assert np.array_equal(got[("ColorMSE", True, "ycc")], orc.color_mse(cola, colb, o.nn_idx[0], "ycc"))
+        assert np.array_equal(got[("ColorMSE", False, "ycc")], orc.color_mse(colb, cola, o.nn_idx[1], "ycc"))
+        lo, hi = np.minimum(a.min(0), b.min(0)), np.maximum(a.max(0), b.max(0))
+        assert pair._engine.nn_stats(0)["splits"] == int(np.prod(np.floor((hi - lo) / 8.0) + 1)), "the report left the voxel-brick grid"
