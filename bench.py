@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "brute", "grid"])
     ap.add_argument("--content-only", action="store_true",
                     help="profiling runs: time only the `content` record's step (voxelised-surface pair, D1 + Hausdorff) and exit")
+    ap.add_argument("--content-full-only", action="store_true",
+                    help="profiling runs: time only the `content_full` record's step (the same pair, D1 + D2 + colour rows) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip full_report / cold_pair / brute / end_to_end (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying a hipGraph")
@@ -238,8 +240,60 @@ def main():
                             "longdress files are not in the container), D1 MSE / PSNR / Hausdorff, both directions + symmetric; "
                             "distances only, so the searches run on the voxel bricks (pccm_vox.hip; PCCM_VOX=0: the per-thread lattice kernel)"}
 
+    def content_full_record(steps):
+        """The configs[4]-shaped report on PCC-like content with everything resident: D1 + D2 (the matched point's normal: the clouds
+        differ in size) + colour (ycc) + Hausdorff rows, i.e. searches that must return the matched ROW."""
+        ca, cb = synth_content()
+        rng = np.random.default_rng(77)
+
+        def unit(n):
+            g = rng.standard_normal((n, 3)).astype(np.float32)
+            return (g / np.linalg.norm(g, axis=1, keepdims=True)).astype(np.float32)
+
+        def colours(p):
+            c = np.stack([128 + 100 * np.sin(p[:, 0] / 37.0), 128 + 100 * np.cos(p[:, 1] / 23.0), 128 + 90 * np.sin(p[:, 2] / 51.0)], 1)
+            u8 = np.clip(np.rint(c + rng.normal(0, 6, c.shape)), 0, 255).astype(np.uint8)
+            return u8
+
+        pa, pb = PointCloud(ca, unit(len(ca)), colours(ca) / 255.0), PointCloud(cb, unit(len(cb)), colours(cb) / 255.0)
+        copts = CalculateOptions(color="ycc", hausdorff=True, point_to_plane=True)
+        with CloudPair(pa, pb, extent=[511.0, 322.0, 505.0], device=local, nn_engine=args.engine, normal_index="neighbour",
+                       use_graph=not args.no_graph) as cp:
+            ce = cp._engine
+
+            def cstep():
+                cp.recompute()
+                return MetricCalculator(cp).calculate(transform_options(copts)).as_dict()
+
+            for _ in range(4):
+                cstep()
+            ce.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                cres = cstep()
+            ce.sync()
+            dt = (time.perf_counter() - t0) / steps
+            cp._use_graph = False
+            ce.profile(True)
+            ce.profile_reset()
+            for _ in range(5):
+                cstep()
+            ce.sync()
+            kus = {k: round(ce.profile_get(k)[0] / 5 * 1e3, 1) for k in nat.KERNEL_CLASSES if ce.profile_get(k)[1]}
+            ce.profile(False)
+            return {"ms_per_step": round(dt * 1e3, 4), "value": round((len(ca) + len(cb)) / dt / 1e6, 2), "unit": "Mpoints/s",
+                    "points": [len(ca), len(cb)], "rows": len(cres), "kernel_us_per_step": kus, "grid_cells": ce.nn_stats(0)["splits"],
+                    "d2_mse_left": float(cres[("GeoMSE", True, True)]), "color_mse_left_y": float(cres[("ColorMSE", True, "ycc")][0]),
+                    "note": "the content pair with unit normals and uchar colours resident: every row of --color ycc --hausdorff "
+                            "--point-to-plane --normal-index neighbour (32 rows: D1, D2 with the matched point's normal, colour, Hausdorff, "
+                            "the self search); matched rows come from the voxel-brick search (round 4; PCCM_VOX=0: a rebuilt grid + the "
+                            "per-thread lattice kernel)"}
+
     if args.content_only:
         print(json.dumps({"content": content_record(args.steps or 50)}), flush=True)
+        return
+    if args.content_full_only:
+        print(json.dumps({"content_full": content_full_record(args.steps or 50)}), flush=True)
         return
 
     n = args.points
@@ -419,6 +473,7 @@ def main():
 
         # (1b) PCC-like content: voxelised surfaces take the per-thread search, not the brick kernel
         line["content"] = content_record(30)
+        line["content_full"] = content_full_record(20)
 
         # (2) end to end, for the record (never `value`): a FRESH pair per iteration -- upload of both clouds and their
         # normals from pageable host memory, ingest, both sweeps, the same report -- through the pooled context

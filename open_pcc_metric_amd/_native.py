@@ -287,6 +287,7 @@ def _as_rows(a, what: str) -> Tuple[object, int, int, int, object]:
 
 class Engine:
     """One libpccm context = one GPU.  Method names mirror include/pccm.h."""
+    keeps_self_search = True      # pccm_set_cloud(1, ...) leaves cloud 0 and its self search untouched (CloudPair.with_reconst)
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         self._lib = load()

@@ -255,7 +255,7 @@ class CloudPair:
         self._estimate_normals, self._normals_knn = bool(estimate_normals), int(normals_knn)
         self._estimated = [False, False]
         self._xchg, self._xchg_wanted = {}, []
-        self._colours_on_device = False
+        self._colours_on_device = [False, False]
         self._colour_red = {}
         self._graph_id = None
         self._last_wanted = None
@@ -285,6 +285,49 @@ class CloudPair:
                 _engine.set_shard(self._coll.rank, self._coll.world)
         self._update_fusion()
         self.recompute()
+
+    def with_reconst(self, reconst_cloud) -> "CloudPair":
+        """The pair of THIS pair's origin cloud and another reconstructed cloud -- one reference against several decoded
+        versions (BASELINE.json configs[4]; the reference runs its command line once per version, handler.py:57-66, and
+        repeats everything).  What belongs to the origin cloud alone is kept: its points, normals (given or estimated,
+        cloud_pair.py:61-64) and colours in HBM, its spatial order, ``get_extent()`` (cloud_pair.py:111-112) and the self
+        search behind ``get_boundary_sqrt_distances()`` (cloud_pair.py:108-109); only the new cloud is uploaded and the two
+        directional searches run.  The GPU context moves to the new pair: this one is closed.  Rows are the same, bit for
+        bit, as those of a fresh ``CloudPair(origin_cloud, reconst_cloud)``."""
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            raise RuntimeError("this CloudPair has been closed")
+        if self._coll.sharded or not hasattr(eng, "nn_pair"):
+            # (a sharded pair keeps nothing that pays: every rank would have to agree on what is resident)
+            kw = dict(nn_engine=self.nn_engine, normal_index=self.normal_index, extent=self._extent, use_graph=self._use_graph,
+                      estimate_normals=self._estimate_normals, normals_knn=self._normals_knn)
+            group, owns = self._coll.group, self._owns_engine
+            self.__dict__.pop("_engine")
+            if owns:
+                nat.release_engine(eng)
+                return CloudPair(self.clouds[0], reconst_cloud, group=group, **kw)
+            return CloudPair(self.clouds[0], reconst_cloud, group=group, _engine=eng, **kw)
+        new = object.__new__(CloudPair)
+        new.__dict__.update({k: v for k, v in self.__dict__.items() if k != "_engine"})
+        new.clouds = (self.clouds[0], reconst_cloud)
+        new._estimated = [self._estimated[0], False]
+        new._colours_on_device = [self._colours_on_device[0], False]
+        new._xchg, new._xchg_wanted, new._colour_red = {}, [], {}
+        new._graph_id, new._last_wanted = None, None
+        keep_self = bool(self.__dict__.get("_self_done")) and bool(getattr(eng, "keeps_self_search", False))
+        self_total = self.__dict__.get("_totals", {}).get((nat.DIR_SELF, nat.METRIC_D1)) if keep_self else None
+        self.__dict__.pop("_engine")                     # moved: this pair is closed, the context is not handed back
+        self._owns_engine = False
+        new._engine = eng
+        eng.set_cloud(1, reconst_cloud.points)               # (the library keeps cloud 0, everything it owns and its self search)
+        if _has_normals(reconst_cloud):
+            eng.set_normals(1, reconst_cloud.normals)
+        new._update_fusion()
+        new.recompute()
+        new._self_done = keep_self
+        if self_total is not None:
+            new._totals[(nat.DIR_SELF, nat.METRIC_D1)] = self_total
+        return new
 
     def close(self) -> None:
         """Hand the GPU context back (it is reused by the next pair); the pair must not be used afterwards."""
@@ -549,14 +592,15 @@ class CloudPair:
         return self._own_colours(1)
 
     def _ensure_colours(self) -> None:
-        if not self._colours_on_device:
-            for k, cloud in enumerate(self.clouds):
-                u8 = getattr(cloud, "colors_u8", None)
-                if u8 is not None and hasattr(self._engine, "set_colors_u8"):
-                    self._engine.set_colors_u8(k, u8)        # file colours: 3 B/point up, the k / 255.0 redone on the device
-                else:
-                    self._engine.set_colors(k, _host_rows(cloud.colors))
-            self._colours_on_device = True
+        for k, cloud in enumerate(self.clouds):
+            if self._colours_on_device[k]:
+                continue
+            u8 = getattr(cloud, "colors_u8", None)
+            if u8 is not None and hasattr(self._engine, "set_colors_u8"):
+                self._engine.set_colors_u8(k, u8)        # file colours: 3 B/point up, the k / 255.0 redone on the device
+            else:
+                self._engine.set_colors(k, _host_rows(cloud.colors))
+            self._colours_on_device[k] = True
 
     def _colour_rows_arg(self, direction: int):
         """Neighbour rows for the colour kernels: the context's own (None) unless the search was sharded."""
@@ -594,6 +638,8 @@ class CloudPair:
         requests = []
         for item in wanted:
             if item == "boundary":
+                if self._self_done and (nat.DIR_SELF, nat.METRIC_D1) in self._totals:
+                    continue                              # inherited with the origin cloud (with_reconst): nothing to reduce again
                 if not self._self_done:
                     eng.nn(nat.DIR_SELF, self.nn_engine)
                     self._self_done = True

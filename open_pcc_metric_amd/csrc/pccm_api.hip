@@ -309,7 +309,7 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
     for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
     DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->stats, &ctx->staging,
-                      &ctx->counters, &ctx->color_cols, &ctx->color_idx, &ctx->rescan_part, &ctx->tail_sync};
+                      &ctx->counters, &ctx->color_cols, &ctx->color_idx, &ctx->colsum_scratch, &ctx->rescan_part, &ctx->tail_sync};
     for (DevBuf *b : bufs) free_buf(*b);
     for (auto &g : ctx->graphs) graph_free(g);
     for (auto &s : ctx->slots) {
@@ -335,7 +335,13 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
     Cloud &c = ctx->cloud[which];
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     drop_cloud(c);                                   // its normals and colours go with it
-    for (int d = 0; d < 3; ++d) { ctx->nn[d].valid = false; ctx->nn_gen[d]++; }
+    // (a new cloud 1 leaves the self search of cloud 0 -- cloud_pair.py:108-109 -- as valid as it was: one reference cloud
+    // against several decoded ones, BASELINE configs[4], keeps it, see CloudPair.with_reconst)
+    for (int d = 0; d < 3; ++d) {
+        if (which == 1 && d == PCCM_DIR_SELF) continue;
+        ctx->nn[d].valid = false;
+        ctx->nn_gen[d]++;
+    }
     ctx->epoch++;
     c.version++;
     const int64_t n_pad = (n + kScanTile - 1) / kScanTile * kScanTile;
@@ -1687,12 +1693,12 @@ int pccm_nn_stats(pccm_ctx *ctx, int dir, int64_t out[3])
     NNResult *res;
     int rc = need_nn(ctx, dir, &it, &se, &res);
     if (rc) return rc;
-    uint32_t nf = 0;
-    PCCM_HIP(hipMemcpyAsync(&nf, res->nflag_dev, sizeof(nf), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t nf[2] = {0, 0};
+    PCCM_HIP(hipMemcpyAsync(nf, res->nflag_dev, sizeof(nf), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    out[0] = nf;
+    out[0] = nf[0];
     out[1] = res->stats[1];
-    out[2] = res->stats[2];
+    out[2] = res->stats[2] ? res->stats[2] : (int64_t)nf[1];     // brute-force engine: scanned pairs; grid engine: queries its ring-1 kernel left to the tail
     return PCCM_OK;
 }
 

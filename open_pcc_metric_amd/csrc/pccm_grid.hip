@@ -1332,7 +1332,9 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         const NNResult &res = ctx->nn[dir];
         if (res.end <= res.begin) continue;
         const Cloud &it = ctx->cloud[dir == PCCM_DIR_RIGHT ? 1 : 0], &se = ctx->cloud[dir == PCCM_DIR_LEFT ? 1 : 0];
-        const bool rows = ctx->want_idx || force_idx || fused_mode(ctx, dir, it, se) >= 0;
+        // (pccm_nn_want_idx speaks for the two directions colour metrics and getters read; the self search is read for its
+        // distances -- cloud_pair.py:108-109 -- and returns rows only to a caller who asks for them explicitly)
+        const bool rows = dir == PCCM_DIR_SELF ? force_idx != 0 : (ctx->want_idx || force_idx || fused_mode(ctx, dir, it, se) >= 0);
         if (rows && dir == PCCM_DIR_SELF) want_vox = 0;
         else if (rows) want_vox = 2;
     }
@@ -1407,7 +1409,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         const bool defer = gr.vox || (!defer_off && gr.rec32 && fm != PCCM_NORMAL_NEIGHBOUR);
         if (defer) res.rec_stride = 2;
         res.rec_layout = defer ? 1 : 0;
-        res.no_rows = gr.vox && !(gr.vox_rows && want_vox == 2);
+        res.no_rows = gr.vox && !(gr.vox_rows && want_vox == 2 && dir != PCCM_DIR_SELF);
         J.out.rec = (double *)res.rec.p;
         J.out.stride = res.rec_stride;
         J.out.nrm = fm >= 0 ? se.nrm64 : nullptr;
@@ -1492,7 +1494,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         bool tail_launch = true;                 // a ring-1 kernel ran: its tails and the exact rescan share one launch
         if (gr.vox) {
             ProfScope ps(ctx, PCCM_K_GRID_QUERY);
-            if ((rc = launch_vox_query(ctx, jobs, g, self, gr.vox_rows && want_vox == 2))) return rc;      // (queries with nothing within 8 voxels: the general search)
+            if ((rc = launch_vox_query(ctx, jobs, g, self, gr.vox_rows && want_vox == 2 && !self))) return rc;      // (queries with nothing within 8 voxels: the general search)
         } else if (use_coop(ctx)) {
             ProfScope ps(ctx, PCCM_K_GRID_QUERY);
             if (gr.rec32) {

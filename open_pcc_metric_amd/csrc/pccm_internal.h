@@ -199,6 +199,8 @@ struct pccm_ctx {
     pccm::DevBuf tail_sync;               // k_grid_tail: retired-entry counts + ticket, for the normal and the self pass
     bool tail_sync_clean = false;
     pccm::DevBuf color_cols, color_idx;   // colour pass: squares as three columns / caller-supplied neighbour rows
+    pccm::DevBuf colsum_scratch;          // ... the column sums' chunk guesses and sub-chunk totals (pccm_color.hip)
+    bool colsum_configured = false;       // k_colsum_chain's LDS opt-in was set on this context's device
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
     pccm::DevBuf g_bins, g_tmp;            // grid build: per-tile bin histogram + scan state; bin-partitioned records
@@ -208,7 +210,6 @@ struct pccm_ctx {
     // answering wrongly in silence; every call that hands results to the caller checks it behind its wait (check_device_errors)
     uint32_t *host_err = nullptr;
     bool bins_clean = false;   // the build's bin cursors (head of g_bins) are zero on the stream
-    bool colsum_configured = false;        // k_color_colsum's dynamic-LDS opt-in was set on this context's device
     int want_idx = 1;                      // pccm_nn_want_idx: searches store the matched row with every result
     int fuse_mode[3] = {-1, -1, -1};       // pccm_nn_fuse: normal mode of the D2 projection fused into the search, per direction
     pccm::ReduceSlot slots[8];

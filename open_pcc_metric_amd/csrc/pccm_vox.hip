@@ -175,13 +175,13 @@ __global__ __launch_bounds__(256) void k_vox_bricks(VoxBuild vb, GridGeom g)
     }
 }
 
-constexpr int kVoxTies = 8;                         // equidistant nearest voxels a query may have before it is left to the tail kernels
+constexpr int kVoxTies = 12;                        // equidistant nearest voxels a query may have before it is left to the tail kernels
 
 template <bool SELF, bool ROWS>
 __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
 {
     static_assert(!(SELF && ROWS), "the self search with matched rows takes the lattice kernel");
-    __shared__ uint32_t s_hit[ROWS ? kVoxTies * 64 : 1];   // ROWS: the lanes' equidistant nearest voxels, packed (below)
+    __shared__ uint16_t s_hit[ROWS ? kVoxTies * 64 : 1];   // ROWS: the lanes' equidistant nearest voxels, packed (section 5)
     __shared__ uint32_t s_cs[40];                 // 9 rows x 4 cell starts of the searched cloud, [36], [37]: the cell's query range
     __shared__ uint32_t s_brick[27 * 16];         // occupancy bricks of the 27 cells (zero: empty / outside)
     __shared__ __attribute__((aligned(16))) uint32_t s_rows[576];   // x-rows of the staged 24^3: bit x + 1 of word [Z * 24 + Y]
@@ -310,7 +310,9 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
                 }
             }
             if (ROWS) {
-                // ---- 5. the matched row: every voxel at exactly the nearest distance, then the smallest row among their points
+                // ---- 5. the matched row: every voxel at exactly the nearest distance, then the smallest row among their points.
+                //      (a) a second walk over the rows within reach notes the hits -- {dy, dz, dx, side} in 16 bits, nothing else:
+                //      the lanes hit at different rows, and whatever a hit costs is paid by the whole wave at every row;
                 const uint32_t d2 = best >> 8;
                 const bool ok = have && d2 <= 64u;
                 uint32_t cnt = 0u;
@@ -321,51 +323,66 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const uint32_t r2 = ee[u] >> 16;
-                        if (!(ok && r2 <= d2)) continue;
                         const uint32_t rem = d2 - r2;
-                        const uint32_t dx = (uint32_t)(__builtin_sqrtf((float)rem) + 0.5f);
-                        if (dx * dx != rem) continue;                             // no voxel of this row lies at exactly d2
+                        const uint32_t dx = (uint32_t)(__builtin_sqrtf((float)(int)rem) + 0.5f);
+                        if (!(ok && r2 <= d2 && dx * dx == rem)) continue;        // no voxel of this row lies at exactly d2 from this query
                         const int dz = (int)(ee[u] & 0xffu) - 8, dy = (int)((ee[u] >> 8) & 0xffu) - 8;
                         const uint32_t w = s_rows[base + dz * 24 + dy];
-                        const int Y = ly + dy, Z = lz + dz;                       // 0 .. 23: |dy|, |dz| <= 8 around 8 .. 15
-                        const int rr = (Y >> 3) + 3 * (Z >> 3);
-#pragma unroll
-                        for (int side = 0; side < 2; ++side) {
-                            if (side == 1 && dx == 0u) continue;
-                            const int X = side == 0 ? lx + (int)dx : lx - (int)dx;  // 0 .. 23 likewise
-                            if (!((w >> (X + 1)) & 1u)) continue;
-                            const int b = rr * 3 + (X >> 3), v = (X & 7) + 8 * (Y & 7) + 64 * (Z & 7);
-                            uint32_t rank = (uint32_t)__popc(s_brick[b * 16 + (v >> 5)] & ((1u << (v & 31)) - 1u));
-                            for (int wv = 0; wv < (v >> 5); ++wv) rank += (uint32_t)__popc(s_brick[b * 16 + wv]);
-                            if (cnt < (uint32_t)kVoxTies) s_hit[cnt * 64u + (uint32_t)lane] = ((uint32_t)b << 18) | (rank << 9) | (uint32_t)v;
+                        const uint32_t code = (ee[u] & 0x1fu) | (((ee[u] >> 8) & 0x1fu) << 5) | (dx << 10);   // dz + 8 | (dy + 8) << 5 | dx << 10 (dx <= 8)
+                        if ((w >> (L + (int)dx)) & 1u) {                           // (L + dx <= 24, L - dx >= 1: never a sentinel bit)
+                            if (cnt < (uint32_t)kVoxTies) s_hit[cnt * 64u + (uint32_t)lane] = (uint16_t)code;
+                            ++cnt;
+                        }
+                        if (dx && ((w >> (L - (int)dx)) & 1u)) {
+                            if (cnt < (uint32_t)kVoxTies) s_hit[cnt * 64u + (uint32_t)lane] = (uint16_t)(code | 0x8000u);
                             ++cnt;
                         }
                     }
                 }
-                // the candidates' rows: all gathers in flight together, then the smallest
+                //      (b) hit j of every lane at once: its voxel, the voxel's rank among the set bits of its cell's brick (the
+                //      sixteen words by four wide reads, v_bcnt with a mask per word), the gather of that voxel's smallest row --
+                //      all gathers of a query in flight together;
                 int rows_of[kVoxTies];
+                uint32_t vox_of[kVoxTies];
 #pragma unroll
                 for (int j = 0; j < kVoxTies; ++j) {
                     rows_of[j] = 0x7fffffff;
+                    vox_of[j] = 0u;
                     if ((uint32_t)j < cnt && cnt <= (uint32_t)kVoxTies) {
-                        const uint32_t h = s_hit[j * 64 + lane], b = h >> 18, r = b / 3u;
-                        rows_of[j] = J.vminrow[s_cs[r * 4u + (b - 3u * r)] + ((h >> 9) & 0x1ffu)];
+                        const uint32_t h = s_hit[j * 64 + lane];
+                        const int dz = (int)(h & 0x1fu) - 8, dy = (int)((h >> 5) & 0x1fu) - 8, dxs = (int)((h >> 10) & 0xfu);
+                        const int X = (h & 0x8000u) ? lx - dxs : lx + dxs, Y = ly + dy, Z = lz + dz;      // 0 .. 23 each
+                        const int rr = (Y >> 3) + 3 * (Z >> 3), bb = rr * 3 + (X >> 3), v = (X & 7) + 8 * (Y & 7) + 64 * (Z & 7);
+                        const uint4 *bw = reinterpret_cast<const uint4 *>(s_brick + bb * 16);
+                        uint32_t rank = 0u;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const uint4 t = bw[q4];
+                            const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int wv = 4 * q4 + i, sh = v - 32 * wv;                  // bits of word wv below voxel v: all, some or none
+                                const uint32_t m = sh >= 32 ? 0xffffffffu : (sh <= 0 ? 0u : (1u << sh) - 1u);
+                                rank += (uint32_t)__popc(tw[i] & m);
+                            }
+                        }
+                        rows_of[j] = J.vminrow[s_cs[rr * 4 + (X >> 3)] + rank];
+                        vox_of[j] = (uint32_t)X | ((uint32_t)Y << 5) | ((uint32_t)Z << 10);
                     }
                 }
+                //      (c) the smallest row wins (rows are unique: no tie is left).
                 int wrow = 0x7fffffff;
-                uint32_t wh = 0u;
+                uint32_t wv3 = 0u;
 #pragma unroll
                 for (int j = 0; j < kVoxTies; ++j)
                     if (rows_of[j] < wrow) {
                         wrow = rows_of[j];
-                        wh = s_hit[j * 64 + lane];
+                        wv3 = vox_of[j];
                     }
                 if (have) {
                     if (ok && cnt >= 1u && cnt <= (uint32_t)kVoxTies && wrow != 0x7fffffff) {
-                        const uint32_t b = wh >> 18, v = wh & 0x1ffu, r = b / 3u;
-                        const int X = 8 * (int)(b - 3u * r) + (int)(v & 7u), Y = 8 * (int)(r % 3u) + (int)((v >> 3) & 7u),
-                                  Z = 8 * (int)(r / 3u) + (int)(v >> 6);
-                        store_result_rec(J.out, __float_as_int(q.w), (float)(rx0 + X), (float)(ry0 + Y), (float)(rz0 + Z), wrow);
+                        store_result_rec(J.out, __float_as_int(q.w), (float)(rx0 + (int)(wv3 & 31u)), (float)(ry0 + (int)((wv3 >> 5) & 31u)),
+                                         (float)(rz0 + (int)(wv3 >> 10)), wrow);
                     } else {
                         // nothing within 8 voxels, more equidistant neighbours than the list holds, or (cannot happen) a set bit
                         // without a row: the general kernels decide

@@ -1,6 +1,6 @@
 """Command line -- same flags and report text as ``python -m open_pcc_metric`` (handler.py:4-71).
 
-    python -m open_pcc_metric_amd --ocloud A.ply --pcloud B.ply [--color rgb|ycc] [--hausdorff]
+    python -m open_pcc_metric_amd --ocloud A.ply --pcloud B.ply [--pcloud C.ply ...] [--color rgb|ycc] [--hausdorff]
                                   [--point-to-plane] [--csv]
 
 Extra, optional flags (defaults reproduce the reference): ``--device``, ``--engine``,
@@ -17,7 +17,9 @@ import click
 
 @click.command()
 @click.option("--ocloud", required=True, type=str, help="Original point cloud.")
-@click.option("--pcloud", required=True, type=str, help="Processed point cloud.")
+@click.option("--pcloud", required=True, type=str, multiple=True,
+              help="Processed point cloud.  May be given several times: one report per processed cloud, printed one after the other "
+                   "exactly as separate runs would print them, with the original cloud read, uploaded and analysed once.")
 @click.option("--color", required=False, type=click.Choice(["rgb", "ycc"]), help="Report color distortions as well.")
 @click.option("--hausdorff", required=False, is_flag=True,
               help="Report hausdorff metric as well. If --point-to-plane is provided, "
@@ -39,19 +41,27 @@ def cli(ocloud, pcloud, color, hausdorff, point_to_plane, csv, device, engine, n
     from .io import read_point_cloud
     from .options import CalculateOptions, transform_options
 
-    ocloud_cloud, pcloud_cloud = map(read_point_cloud, (ocloud, pcloud))
-    cloud_pair = CloudPair(ocloud_cloud, pcloud_cloud, device=device, nn_engine=engine, normal_index=normal_index,
-                           extent=list(extent) if extent else None)
-    calculator = MetricCalculator(cloud_pair)
+    ocloud_cloud = read_point_cloud(ocloud)
     options = CalculateOptions(color=color, hausdorff=hausdorff, point_to_plane=point_to_plane)
-    result = calculator.calculate(transform_options(options)).as_df()
-    print(result.to_csv() if csv else result.to_string())
-    if tie_exposure:                       # stderr: stdout stays byte-identical to the reference's report
-        for is_left in (True, False):
-            t = cloud_pair.tie_exposure(is_left, point_to_plane)
-            line = (f"tie exposure ({t['direction']}): {t['tied_queries']} of {t['queries']} points have several equidistant nearest "
-                    f"neighbours ({100.0 * t['tie_rate']:.3f} %, up to {t['max_multiplicity']})")
-            if point_to_plane:
-                line += (f"; point-to-plane mse in [{t['d2_mse_min']!r}, {t['d2_mse_max']!r}] over all tie orders, "
-                         f"reported {t['d2_mse_pick']!r} (smallest row)")
-            click.echo(line, err=True)
+    cloud_pair = None
+    for path in pcloud:
+        pcloud_cloud = read_point_cloud(path)
+        if cloud_pair is None:
+            cloud_pair = CloudPair(ocloud_cloud, pcloud_cloud, device=device, nn_engine=engine, normal_index=normal_index,
+                                   extent=list(extent) if extent else None)
+        else:
+            cloud_pair = cloud_pair.with_reconst(pcloud_cloud)     # the original cloud stays in HBM with all that belongs to it
+        calculator = MetricCalculator(cloud_pair)
+        result = calculator.calculate(transform_options(options)).as_df()
+        print(result.to_csv() if csv else result.to_string())
+        if tie_exposure:                       # stderr: stdout stays byte-identical to the reference's report
+            for is_left in (True, False):
+                t = cloud_pair.tie_exposure(is_left, point_to_plane)
+                line = (f"tie exposure ({t['direction']}): {t['tied_queries']} of {t['queries']} points have several equidistant nearest "
+                        f"neighbours ({100.0 * t['tie_rate']:.3f} %, up to {t['max_multiplicity']})")
+                if point_to_plane:
+                    line += (f"; point-to-plane mse in [{t['d2_mse_min']!r}, {t['d2_mse_max']!r}] over all tie orders, "
+                             f"reported {t['d2_mse_pick']!r} (smallest row)")
+                click.echo(line, err=True)
+    if cloud_pair is not None:
+        cloud_pair.close()

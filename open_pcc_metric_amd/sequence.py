@@ -1,7 +1,8 @@
 """Many pairs, many GPUs: the frames of a sequence (or the decoded versions of a frame) are independent units.
 
 The reference evaluates one pair per process run (handler.py:44-71).  A codec study evaluates hundreds; with one
-process per GPU (``torch.distributed``) those shard by *pair*, not by point: rank r takes pairs r, r + W, r + 2W, ...
+process per GPU (``torch.distributed``) those shard by *pair*, not by point: rank r takes chains r, r + W, r + 2W, ... (a chain =
+consecutive pairs that share their origin cloud: one reference against several decoded versions keeps the reference resident)
 and runs each whole report on its own GPU -- no collective in the data path (the per-pair context pool of
 ``_native.acquire_engine`` makes consecutive pairs cheap), one small ``all_gather_object`` of the finished rows at the
 end.  That is the weak-scaling way to use a node; sharding the query axis of ONE pair (``CloudPair(group=...)``) is the
@@ -35,25 +36,47 @@ def evaluate_pairs(pairs: typing.Iterable[typing.Tuple[typing.Any, typing.Any]],
     if device is None and world > 1:
         import os
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    def report(item):
-        origin, reconst = item() if callable(item) else item
-        with CloudPair(origin, reconst, device=device, **pair_kwargs) as pair:
-            return MetricCalculator(pair).calculate(transform_options(options)).as_dict()
+    def run_chain(chain):
+        """The items of one chain, one after the other on one context; consecutive items with the SAME origin cloud object keep
+        it resident (CloudPair.with_reconst: upload, normals, extent and self search of the origin happen once)."""
+        out, pair, prev_origin = {}, None, None
+        try:
+            for i, item in chain:
+                origin, reconst = item() if callable(item) else item
+                if pair is not None and origin is prev_origin:
+                    pair = pair.with_reconst(reconst)
+                else:
+                    if pair is not None:
+                        pair.close()
+                    pair = CloudPair(origin, reconst, device=device, **pair_kwargs)
+                out[i] = MetricCalculator(pair).calculate(transform_options(options)).as_dict()
+                prev_origin = origin
+        finally:
+            if pair is not None:
+                pair.close()
+        return out
 
-    todo, total = [], 0
+    # chains: runs of consecutive items that share their origin cloud (by identity; items given as callables are loaded by
+    # the rank that owns them, so each stands alone).  Ranks and worker threads take whole chains.
+    chains, total, last_origin = [], 0, None
     for i, item in enumerate(pairs):
         total = i + 1
-        if i % world == rank:
-            todo.append((i, item))
+        origin = None if callable(item) else item[0]
+        if chains and origin is not None and origin is last_origin:
+            chains[-1].append((i, item))
+        else:
+            chains.append([(i, item)])
+        last_origin = origin
+    todo = [c for k, c in enumerate(chains) if k % world == rank]
     mine: typing.Dict[int, typing.Dict] = {}
     if workers > 1 and len(todo) > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=int(workers)) as pool:
-            for (i, _), rows in zip(todo, pool.map(report, [item for _, item in todo])):
-                mine[i] = rows
+            for rows in pool.map(run_chain, todo):
+                mine.update(rows)
     else:
-        for i, item in todo:
-            mine[i] = report(item)
+        for chain in todo:
+            mine.update(run_chain(chain))
     if world == 1:
         return [mine[i] for i in range(total)]
     shares: typing.List[typing.Optional[dict]] = [None] * world
