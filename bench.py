@@ -485,6 +485,14 @@ def main():
             with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine) as fresh:
                 MetricCalculator(fresh).calculate(headline_metrics()).as_dict()
         dt = (time.perf_counter() - t_e2e) / reps
+        # ... and with every upload in front of the first search (round 3's order), to see what the new order hides
+        t_ser = 0.0
+        for it in range(reps + 1):
+            if it == 1:
+                t_ser = time.perf_counter()
+            with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine, _uploads_first=True) as fresh:
+                MetricCalculator(fresh).calculate(headline_metrics()).as_dict()
+        dt_serial = (time.perf_counter() - t_ser) / reps
         h2d_bytes = a.nbytes + b.nbytes + na.nbytes + nb.nbytes
         # the upload alone, same buffers, same context: what PCIe and the pageable-memory path allow
         ue = nat.Engine(local)
@@ -495,11 +503,19 @@ def main():
         ue.sync()
         up = (time.perf_counter() - t_up) / reps
         ue.close()
+        # the same fresh pair with the points alone uploaded before the searches start (the round-3 order for comparison is gone:
+        # CloudPair announces normals and flushes them behind the sweeps); what a resident pair costs for the same work once,
+        # eagerly (no graph), is the non-PCIe share
         line["end_to_end"] = {"ms_per_pair": round(dt * 1e3, 4), "value": round(2 * n / dt / 1e6, 2), "unit": "Mpoints/s",
                               "h2d_ms": round(up * 1e3, 4), "h2d_bytes": int(h2d_bytes), "h2d_GBs": round(h2d_bytes / up / 1e9, 1),
-                              "note": "fresh CloudPair per iteration: H2D of 2 clouds + 2 normal sets (pageable fp32, 48 MB), ingest incl. the "
-                                      "spatial ordering of both clouds, sweeps, report; h2d_ms = the four uploads + ingests alone (PCIe "
-                                      "Gen5 x16: 63 GB/s spec -> 0.76 ms for these bytes at best)"}
+                              "ms_per_pair_uploads_first": round(dt_serial * 1e3, 4), "hidden_ms": round((dt_serial - dt) * 1e3, 4),
+                              "note": "fresh CloudPair per iteration through the pooled context: H2D of 2 clouds (pageable fp32), ingest, grid "
+                                      "decisions inherited, both sweeps from the caller's row order (no spatial copy: a pair that is searched "
+                                      "once never makes one), the normals' H2D (2 x 12 MB, announced before and flushed behind the sweeps: "
+                                      "pccm_set_normals_deferred) on a copy stream beside them, report; h2d_ms = the four uploads + ingests "
+                                      "alone, serialised (PCIe Gen5 x16: 63 GB/s spec -> 0.76 ms for these bytes at best); ms_per_pair_uploads_first = the "
+                                      "same pair with all four uploads in front of the first search (round 3's order), hidden_ms the difference: "
+                                      "the searches are ~0.13 ms of GPU work, which is all an upload of 0.55 ms can hide"}
 
         # (3) a cold pair: brand-new context (no pooled allocations), nothing inherited from an earlier pair
         # (PCCM_GRID_NO_REUSE=1: the cell-edge decision with its histogram passes and host round trips runs), one report

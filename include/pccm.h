@@ -104,6 +104,15 @@ int pccm_set_cloud(pccm_ctx *ctx, int which, const void *xyz, int64_t n, int dty
  * for PCCM_NORMAL_NEIGHBOUR; PCCM_NORMAL_ROW only needs the rows it indexes. */
 int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype, int on_device);
 
+/* The same for HOST normals, announced now and uploaded later: the library notes the pointer (the array must stay alive and
+ * unchanged until pccm_flush_uploads returns or another call replaces the cloud or its normals) and moves the data when a
+ * call needs it -- or at pccm_flush_uploads -- on a copy stream of its own.  Searches whose results are matched records never
+ * read normals, so a caller that announces, starts the searches and then flushes has the upload run beside them:
+ * handler.py:57-58 of the reference reads both files, then cloud_pair.py:61-80 does everything else; nothing in it orders the
+ * normals before the searches.  Non-finite normals are reported by the call that uploads them (PCCM_E_ARG), not by this one. */
+int pccm_set_normals_deferred(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype);
+int pccm_flush_uploads(pccm_ctx *ctx);
+
 /* Replaces clouds[k].estimate_normals(), cloud_pair.py:61-64 (Open3D EstimateNormals, default
  * KDTreeSearchParamKNN(knn = 30)): per point, the eigenvector of the smallest eigenvalue of the
  * covariance of its knn nearest points of the same cloud (itself included).  Open3D's own arithmetic

@@ -29,7 +29,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
-    "pccm_set_cloud", "pccm_set_normals", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_want_idx", "pccm_nn_fetch",
+    "pccm_set_cloud", "pccm_set_normals", "pccm_set_normals_deferred", "pccm_flush_uploads", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_want_idx", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_tie_exposure", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total", "pccm_reduce_total_many", "pccm_cvec_len", "pccm_reduce_chunks_many", "pccm_finish_chunks",
     "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
@@ -86,6 +86,8 @@ def load() -> ctypes.CDLL:
     lib.pccm_ctx_reset.argtypes = [vp]
     lib.pccm_set_cloud.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_set_normals.argtypes = [vp, i32, vp, i64, i32, i32]
+    lib.pccm_set_normals_deferred.argtypes = [vp, i32, vp, i64, i32]
+    lib.pccm_flush_uploads.argtypes = [vp]
     lib.pccm_set_shard.argtypes = [vp, i32, i32]
     lib.pccm_set_shard_dir.argtypes = [vp, i32, i32, i32]
     lib.pccm_estimate_normals.argtypes = [vp, i32, i32]
@@ -321,7 +323,24 @@ class Engine:
 
     def set_normals(self, which: int, normals) -> None:
         ptr, n, dt, dev, keep = _as_rows(normals, "normals")
+        self.__dict__.setdefault("_deferred", {}).pop(int(which), None)
         _check(self._lib.pccm_set_normals(self._ctx, int(which), ptr, n, dt, dev))
+
+    def set_normals_deferred(self, which: int, normals) -> None:
+        """Announce host normals now, upload them when they are needed or at flush_uploads() -- beside the searches, which do
+        not read them (include/pccm.h).  The array is kept alive here until then; device arrays are set at once."""
+        ptr, n, dt, dev, keep = _as_rows(normals, "normals")
+        if dev:
+            _check(self._lib.pccm_set_normals(self._ctx, int(which), ptr, n, dt, dev))
+            return
+        _check(self._lib.pccm_set_normals_deferred(self._ctx, int(which), ptr, n, dt))
+        self.__dict__.setdefault("_deferred", {})[int(which)] = keep
+
+    def flush_uploads(self) -> None:
+        try:
+            _check(self._lib.pccm_flush_uploads(self._ctx))
+        finally:
+            self.__dict__.get("_deferred", {}).clear()
 
     def set_colors(self, which: int, colors) -> None:
         ptr, n, dt, dev, keep = _as_rows(colors, "colors")

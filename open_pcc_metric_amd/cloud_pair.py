@@ -243,7 +243,7 @@ class CloudPair:
     def __init__(self, origin_cloud, reconst_cloud, *, device: typing.Optional[int] = None,
                  nn_engine: str = "auto", normal_index: str = "row", extent=None, group=None,
                  use_graph: bool = False, estimate_normals: bool = True, normals_knn: int = 30,
-                 shard_mode: str = "direction", _engine=None):
+                 shard_mode: str = "direction", _engine=None, _uploads_first: bool = False):
         if normal_index not in nat.NORMAL_MODES:
             raise ValueError("normal_index must be 'row' or 'neighbour'")
         if nn_engine not in nat.ENGINES:
@@ -270,10 +270,13 @@ class CloudPair:
             self._coll.device = device            # the nccl exchange is staged on the same GPU
         self._engine = _engine
         self._fast_totals = not self._coll.sharded and hasattr(_engine, "reduce_total")   # whole columns finished by one call
+        # Points first; normals are announced and cross PCIe behind the searches, which do not read them (the reference's
+        # constructor orders nothing between the two: cloud_pair.py:61-80) -- see the flush at the end
+        deferred = hasattr(_engine, "set_normals_deferred")
         for k, cloud in enumerate(self.clouds):
             _engine.set_cloud(k, cloud.points)
             if _has_normals(cloud):
-                _engine.set_normals(k, cloud.normals)
+                (_engine.set_normals_deferred if deferred else _engine.set_normals)(k, cloud.normals)
         if shard_mode not in ("direction", "rows"):
             raise ValueError("shard_mode must be 'direction' or 'rows'")
         self._plan = shard_plan(self._coll.world, shard_mode if hasattr(_engine, "set_shard_dir") else "rows")
@@ -284,7 +287,11 @@ class CloudPair:
             else:
                 _engine.set_shard(self._coll.rank, self._coll.world)
         self._update_fusion()
+        if deferred and _uploads_first:
+            _engine.flush_uploads()                       # (A/B for bench.py: everything uploaded before the first search starts)
         self.recompute()
+        if deferred:
+            _engine.flush_uploads()                       # (the searches are running: the normals' upload runs beside them)
 
     def with_reconst(self, reconst_cloud) -> "CloudPair":
         """The pair of THIS pair's origin cloud and another reconstructed cloud -- one reference against several decoded
@@ -320,10 +327,13 @@ class CloudPair:
         self._owns_engine = False
         new._engine = eng
         eng.set_cloud(1, reconst_cloud.points)               # (the library keeps cloud 0, everything it owns and its self search)
+        deferred = hasattr(eng, "set_normals_deferred")
         if _has_normals(reconst_cloud):
-            eng.set_normals(1, reconst_cloud.normals)
+            (eng.set_normals_deferred if deferred else eng.set_normals)(1, reconst_cloud.normals)
         new._update_fusion()
         new.recompute()
+        if deferred:
+            eng.flush_uploads()
         new._self_done = keep_self
         if self_total is not None:
             new._totals[(nat.DIR_SELF, nat.METRIC_D1)] = self_total

@@ -149,6 +149,8 @@ static void free_cloud(Cloud &c)
 static void drop_cloud(Cloud &c)
 {
     c.n = c.n_pad = c.n_nrm = c.n_rgb = 0;
+    c.nrm_deferred = false;
+    c.nrm_host = nullptr;
     c.sp_valid = c.sp_tried = false;
 }
 
@@ -206,6 +208,53 @@ static int upload(pccm_ctx *ctx, const void *src, size_t bytes, int on_device, c
     *dev_src = ctx->staging.p;
     return PCCM_OK;
 }
+
+// upload + widening copy + validation of one cloud's normals on stream `st` (staging buffer `stage` for host sources)
+static int ingest_normals(pccm_ctx *ctx, Cloud &c, int which, const void *nrm, int64_t n, int dtype, int on_device, hipStream_t st, DevBuf &stage)
+{
+    const size_t esz = dtype == PCCM_F32 ? 4 : 8;
+    const void *dsrc = nrm;
+    if (!on_device) {
+        int rc = ensure(ctx, stage, (size_t)n * 3 * esz);
+        if (rc) return rc;
+        PCCM_HIP(hipMemcpyAsync(stage.p, nrm, (size_t)n * 3 * esz, hipMemcpyHostToDevice, st));
+        dsrc = stage.p;
+    }
+    unsigned long long *stats = (unsigned long long *)ctx->stats.p + (st == ctx->stream ? 0 : 12);
+    PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), st));
+    hipStream_t keep = ctx->stream;
+    ctx->stream = st;                                  // (the launcher takes the context's stream)
+    int rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.nrm64, (float *)c.nrm32, stats);
+    ctx->stream = keep;
+    if (rc) return rc;
+    unsigned long long h[3];
+    PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+    PCCM_HIP(hipStreamSynchronize(st));
+    if (h[2] != 0) {
+        c.n_nrm = 0;
+        return fail(PCCM_E_ARG, "normals of cloud %d are not finite", which);      // n_nrm stays 0: no normals
+    }
+    c.n_nrm = n;
+    c.nrm_exact32 = h[1] == 0;      // the search's fused projection then gathers 16 bytes per normal instead of 24 unaligned ones
+    return PCCM_OK;
+}
+
+int normals_ready(pccm_ctx *ctx, Cloud &c)
+{
+    if (!c.nrm_deferred) return PCCM_OK;
+    if (ctx->capturing) {
+        ctx->capture_failed = true;
+        return fail(PCCM_E_STATE, "deferred normals must be uploaded before graph capture: call pccm_flush_uploads first");
+    }
+    if (!ctx->copy_stream) PCCM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    c.nrm_deferred = false;
+    const void *src = c.nrm_host;
+    c.nrm_host = nullptr;
+    const int64_t n = c.n_nrm;
+    c.n_nrm = 0;
+    return ingest_normals(ctx, c, (int)(&c - ctx->cloud), src, n, c.nrm_host_dtype, 0, ctx->copy_stream, ctx->staging2);
+}
+
 
 }  // namespace pccm
 
@@ -280,7 +329,7 @@ int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
     }
     if (!rc) *ctx->host_err = 0u;
     if (!rc && hipEventCreateWithFlags(&ctx->batch_ev, hipEventDisableTiming) != hipSuccess) rc = fail(PCCM_E_HIP, "hipEventCreate failed");
-    if (!rc) rc = ensure(ctx, ctx->stats, 10 * sizeof(unsigned long long));
+    if (!rc) rc = ensure(ctx, ctx->stats, 16 * sizeof(unsigned long long));      // [0..9] the main stream's scratch, [12..14] the copy stream's
     if (!rc && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = fail(PCCM_E_HIP, "hipMemsetAsync failed");
     if (rc) {
@@ -308,7 +357,7 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     ctx->host_err = nullptr;
     for (int k = 0; k < 2; ++k) free_cloud(ctx->cloud[k]);
     for (int d = 0; d < 3; ++d) free_nn(ctx->nn[d]);
-    DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->stats, &ctx->staging,
+    DevBuf *bufs[] = {&ctx->part_b1, &ctx->part_g, &ctx->part_b2, &ctx->val, &ctx->stats, &ctx->staging, &ctx->staging2,
                       &ctx->counters, &ctx->color_cols, &ctx->color_idx, &ctx->colsum_scratch, &ctx->rescan_part, &ctx->tail_sync};
     for (DevBuf *b : bufs) free_buf(*b);
     for (auto &g : ctx->graphs) graph_free(g);
@@ -319,6 +368,7 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
         s.ev = s.wait_ev = nullptr;
     }
     grid_release(ctx);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PCCM_OK;
@@ -398,25 +448,44 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
     ctx->epoch++;
     c.n_nrm = 0;
     c.nrm_exact32 = false;
+    c.nrm_deferred = false;
+    c.nrm_host = nullptr;
     int rc = grow((void **)&c.nrm64, c.cap_nrm, (size_t)n * 3 * sizeof(double));
     if (rc) return rc;
     if ((rc = grow((void **)&c.nrm32, c.cap_nrm32, (size_t)n * sizeof(float4)))) return rc;
-    const size_t esz = dtype == PCCM_F32 ? 4 : 8;
-    const void *dsrc = nullptr;
-    rc = upload(ctx, nrm, (size_t)n * 3 * esz, on_device, &dsrc);
-    if (rc) return rc;
-    unsigned long long *stats = (unsigned long long *)ctx->stats.p;
-    PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
-    rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.nrm64, (float *)c.nrm32, stats);
-    if (rc) return rc;
-    unsigned long long h[3];
-    PCCM_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    return ingest_normals(ctx, c, which, nrm, n, dtype, on_device, ctx->stream, ctx->staging);
+}
+
+int pccm_set_normals_deferred(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
+    if (!nrm || n <= 0) return fail(PCCM_E_ARG, "empty normals");
+    if (dtype != PCCM_F32 && dtype != PCCM_F64) return fail(PCCM_E_ARG, "dtype must be PCCM_F32 or PCCM_F64");
+    Cloud &c = ctx->cloud[which];
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    if (h[2] != 0) {
-        return fail(PCCM_E_ARG, "normals of cloud %d are not finite", which);      // n_nrm stays 0: no normals
+    for (int d = 0; d < 3; ++d) ctx->nn_gen[d]++;
+    ctx->epoch++;
+    c.nrm_exact32 = false;
+    int rc = grow((void **)&c.nrm64, c.cap_nrm, (size_t)n * 3 * sizeof(double));
+    if (rc) return rc;
+    if ((rc = grow((void **)&c.nrm32, c.cap_nrm32, (size_t)n * sizeof(float4)))) return rc;
+    c.n_nrm = n;                                       // announced: the searches know that (and how many) normals exist
+    c.nrm_host = nrm;
+    c.nrm_host_dtype = dtype;
+    c.nrm_deferred = true;
+    return PCCM_OK;
+}
+
+int pccm_flush_uploads(pccm_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    for (int k = 0; k < 2; ++k) {
+        int rc = normals_ready(ctx, ctx->cloud[k]);
+        if (rc) return rc;
     }
-    c.n_nrm = n;
-    c.nrm_exact32 = h[1] == 0;      // the search's fused projection then gathers 16 bytes per normal instead of 24 unaligned ones
     return PCCM_OK;
 }
 
@@ -657,7 +726,8 @@ int pccm_get_normals(pccm_ctx *ctx, int which, double *out)
     NOT_CAPTURING(ctx);
     if (which != 0 && which != 1) return fail(PCCM_E_ARG, "cloud index must be 0 or 1");
     if (!out) return fail(PCCM_E_ARG, "null pointer");
-    const Cloud &c = ctx->cloud[which];
+    Cloud &c = ctx->cloud[which];
+    { int rcn = normals_ready(ctx, c); if (rcn) return rcn; }
     if (c.n_nrm <= 0) return fail(PCCM_E_STATE, "cloud %d has no normals", which);
     PCCM_HIP(hipMemcpyAsync(out, c.nrm64, (size_t)c.n_nrm * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
@@ -892,10 +962,14 @@ int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
     return check_device_errors(ctx);
 }
 
-static int check_normals(const pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int normal_mode)
+static int check_normals(pccm_ctx *ctx, const Cloud &it, const Cloud &se, const NNResult &res, int normal_mode)
 {
     if (normal_mode != PCCM_NORMAL_ROW && normal_mode != PCCM_NORMAL_NEIGHBOUR)
         return fail(PCCM_E_ARG, "bad normal mode %d", normal_mode);
+    {   // whoever checks the normals is about to read them: announced ones (pccm_set_normals_deferred) cross PCIe now
+        int rcn = normals_ready(ctx, const_cast<Cloud &>(se));
+        if (rcn) return rcn;
+    }
     if (se.n_nrm <= 0) return fail(PCCM_E_STATE, "the searched cloud has no normals (pccm_set_normals)");
     // sharded: the test is on the whole iterating cloud, so that every rank raises (or none does) -- a per-shard test
     // would let the low ranks walk into the exchange while the last one raises
@@ -1693,12 +1767,12 @@ int pccm_nn_stats(pccm_ctx *ctx, int dir, int64_t out[3])
     NNResult *res;
     int rc = need_nn(ctx, dir, &it, &se, &res);
     if (rc) return rc;
-    uint32_t nf[2] = {0, 0};
-    PCCM_HIP(hipMemcpyAsync(nf, res->nflag_dev, sizeof(nf), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t nf = 0;
+    PCCM_HIP(hipMemcpyAsync(&nf, res->nflag_dev, sizeof(nf), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    out[0] = nf[0];
+    out[0] = nf;
     out[1] = res->stats[1];
-    out[2] = res->stats[2] ? res->stats[2] : (int64_t)nf[1];     // brute-force engine: scanned pairs; grid engine: queries its ring-1 kernel left to the tail
+    out[2] = res->stats[2];
     return PCCM_OK;
 }
 

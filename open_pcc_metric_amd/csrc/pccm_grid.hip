@@ -1408,6 +1408,7 @@ int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx)
         static const bool defer_off = [] { const char *e = getenv("PCCM_DEFER"); return e && e[0] == '0'; }();
         const bool defer = gr.vox || (!defer_off && gr.rec32 && fm != PCCM_NORMAL_NEIGHBOUR);
         if (defer) res.rec_stride = 2;
+        else if (fm >= 0 && (rc = normals_ready(ctx, ctx->cloud[si]))) return rc;     // the search itself projects: announced normals cross PCIe now
         res.rec_layout = defer ? 1 : 0;
         res.no_rows = gr.vox && !(gr.vox_rows && want_vox == 2 && dir != PCCM_DIR_SELF);
         J.out.rec = (double *)res.rec.p;

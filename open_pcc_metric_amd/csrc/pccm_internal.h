@@ -35,6 +35,12 @@ struct Cloud {
     float4 *nrm32 = nullptr;    // [n_nrm] {nx, ny, nz, -}: the same normals in one aligned 16-byte word each, when nrm_exact32
     bool nrm_exact32 = false;   // every component survives fp64 -> fp32 -> fp64 (file normals usually do; estimated ones do not)
     int64_t n_nrm = 0;
+    // pccm_set_normals_deferred: the normals are announced (n_nrm, buffers) but still lie in the caller's host array; they cross
+    // PCIe when somebody needs them (normals_ready) or at pccm_flush_uploads -- behind the searches, which never read them when
+    // results are matched records (NNOut::layout 1)
+    const void *nrm_host = nullptr;
+    int nrm_host_dtype = 0;
+    bool nrm_deferred = false;
     double *rgb64 = nullptr;    // [n_rgb][3] colours as the caller gave them (RGB in [0, 1])
     int64_t n_rgb = 0;
     // allocations outlive their content (n / n_nrm / n_rgb say what is there): a context that serves one pair after
@@ -187,6 +193,8 @@ struct pccm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t copy_stream = nullptr;     // deferred uploads (pccm_set_normals_deferred): they run beside the main stream's kernels
+    pccm::DevBuf staging2;                 // ... through a staging buffer of their own
     pccm::Cloud cloud[2];
     // query-axis shard per direction (pccm_set_shard / pccm_set_shard_dir): this context owns the rows shard_of(n, rank,
     // world) of the iterating cloud; world 0 = none of them (another group of ranks searches that direction)
@@ -269,7 +277,8 @@ int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the cu
 int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)
 int estimate_normals(pccm_ctx *ctx, int which, int k);
 int tie_exposure(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, const NNResult &res, int normal_mode, double out[8]);
-int check_device_errors(pccm_ctx *ctx);           // PCCM_E_STATE when a kernel raised the context's device error word
+int check_device_errors(pccm_ctx *ctx);
+int normals_ready(pccm_ctx *ctx, Cloud &c);       // uploads normals announced by pccm_set_normals_deferred (no-op otherwise)           // PCCM_E_STATE when a kernel raised the context's device error word
 // exact rescan of the flagged queries of njobs <= 2 results (k2b_fallback)
 int launch_fallback(pccm_ctx *ctx, int njobs, const Cloud *const *its, const Cloud *const *ses, NNResult *const *ress, bool self);
 

@@ -431,6 +431,8 @@ int estimate_normals(pccm_ctx *ctx, int which, int k)
     if ((rc = grow((void **)&c.nrm64, c.cap_nrm, (size_t)c.n * 3 * sizeof(double)))) return rc;
     c.n_nrm = c.n;
     c.nrm_exact32 = false;
+    c.nrm_deferred = false;
+    c.nrm_host = nullptr;
     for (int d = 0; d < 3; ++d) ctx->nn_gen[d]++;      // pending D2 reductions would use stale normals
     ctx->epoch++;
     if ((rc = ensure(ctx, ctx->g_cell_of, (size_t)c.n * sizeof(uint32_t)))) return rc;   // reused: points left to the full scan

@@ -12,7 +12,7 @@ for rows in (False, True):
     for _ in range(3):
         e.drop_caches(); e.nn_pair("grid"); e.nn(2, "grid")
     e.sync()
-    print("rows", rows, "tails", [e.nn_stats(d)["pairs"] for d in (0, 1, 2)], "fallback", [e.nn_stats(d)["fallback_queries"] for d in (0, 1, 2)], "cells", e.nn_stats(0)["splits"])
+    print("rows", rows, "fallback", [e.nn_stats(d)["fallback_queries"] for d in (0, 1, 2)], "cells", e.nn_stats(0)["splits"])
     e.profile(True); e.profile_reset()
     for _ in range(20):
         e.drop_caches(); e.nn_pair("grid")
