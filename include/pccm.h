@@ -305,7 +305,9 @@ int pccm_profile_get(pccm_ctx *ctx, int kernel_class, double *ms_total, int64_t 
 
 /* Bookkeeping of the last pccm_nn() in `dir`: out[0] = queries sent to the exact fallback
  * rescan, out[1] = ref-axis splits of the brute-force scan / number of cells of the grid the
- * grid engine searched, out[2] = (query, ref) pairs evaluated by the brute-force scan (grid: 0). */
+ * grid engine searched, out[2] = (query, ref) pairs evaluated by the brute-force scan (grid: 0).
+ * `dir | PCCM_STATS_TAIL`: out[0] = queries the grid engine's ring-1 kernel left to the tail launch, out[1] = out[2] = 0. */
+#define PCCM_STATS_TAIL 0x10
 int pccm_nn_stats(pccm_ctx *ctx, int dir, int64_t out[3]);
 
 #ifdef __cplusplus

@@ -582,4 +582,7 @@ class Engine:
     def nn_stats(self, direction: int) -> dict:
         out = (ctypes.c_int64 * 3)()
         _check(self._lib.pccm_nn_stats(self._ctx, int(direction), out))
-        return {"fallback_queries": int(out[0]), "splits": int(out[1]), "pairs": int(out[2])}
+        stats = {"fallback_queries": int(out[0]), "splits": int(out[1]), "pairs": int(out[2])}
+        _check(self._lib.pccm_nn_stats(self._ctx, int(direction) | 0x10, out))      # PCCM_STATS_TAIL
+        stats["tail_queries"] = int(out[0])
+        return stats

@@ -1765,8 +1765,18 @@ int pccm_nn_stats(pccm_ctx *ctx, int dir, int64_t out[3])
     if (!out) return fail(PCCM_E_ARG, "null pointer");
     const Cloud *it, *se;
     NNResult *res;
+    const bool tail = (dir & PCCM_STATS_TAIL) != 0;
+    dir &= ~PCCM_STATS_TAIL;
     int rc = need_nn(ctx, dir, &it, &se, &res);
     if (rc) return rc;
+    if (tail) {
+        uint32_t nt = 0;
+        PCCM_HIP(hipMemcpyAsync(&nt, res->nflag_dev + 1, sizeof(nt), hipMemcpyDeviceToHost, ctx->stream));
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+        out[0] = nt;
+        out[1] = out[2] = 0;
+        return PCCM_OK;
+    }
     uint32_t nf = 0;
     PCCM_HIP(hipMemcpyAsync(&nf, res->nflag_dev, sizeof(nf), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));

@@ -38,7 +38,11 @@
 
 namespace pccm {
 
-constexpr uint32_t kTailWaveMax = 16384;   // tails up to this many queries take the wave-per-query kernel
+// tails up to this many queries take the wave-per-query search, longer ones (lattice data, where exact ties defeat the fp32
+// certification of the cooperative kernel) the thread-per-query one.  (16384 until round 4: uniform clouds of 32M points leave
+// 25 000 queries per direction -- 8e-4 of them -- to the tail, and the thread-per-query search took 301 us for them where the
+// wave-per-query one takes ~60)
+constexpr uint32_t kTailWaveMax = 1u << 18;
 
 // per-cell histogram of one cloud (measure_occupancy: cell-edge decision, once per pair of clouds)
 __global__ __launch_bounds__(256) void k_cell_hist(const double *__restrict__ x64, int64_t n, GridGeom g, uint32_t *__restrict__ hist)
@@ -1244,8 +1248,10 @@ static int launch_tail(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, 
     RescanJobs rj;
     int rc = rescan_jobs(ctx, jobs.njobs, its, ses, ress, self, &rj);
     if (rc) return rc;
-    // tails are short (grid-stride loops inside): two waves per SIMD of half the chip are plenty; the rescan's workgroups are few
-    // enough never to keep the tail's off the GPU (see k_grid_tail) and enough to split a cloud finely
+    // the rescan's workgroups are few enough never to keep the tail's off the GPU (see k_grid_tail) and enough to split a cloud finely;
+    // 1024 tail workgroups whatever the size (the grid-stride loops inside take any list): measured at 1M / 8M / 32M points per
+    // cloud -- 2 110 / 13 565 / 51 516 tail queries, ~1e-3 of uniform data -- 256 / 512 / 1024 / 2048 / 4096 workgroups take
+    // 23 / 20 / 15.4 / 18 / 22 us, 119 / 90 / 41 / 43 / 49 us and 421 / 323 / 140 / 142 / 139 us (round 4)
     const int64_t qblocks = (nqmax + 255) / 256;
     TailSync ts;
     ts.n_tail = (uint32_t)(qblocks < 1024 ? qblocks : 1024);

@@ -59,4 +59,4 @@ e.profile(False)
 chk = " ".join(f"{float(v):.17g}" for t in tot for v in t)
 import hashlib  # noqa: E402
 print("RESULT n", n, "eager_ms/step %.4f" % (dt * 1e3), " ".join(f"{k} {v[0] / v[1] * 1e3:.1f}" for k, v in out.items() if v[1]),
-      "| chk", hashlib.sha1(chk.encode()).hexdigest()[:12], "| tag", os.environ.get("TAG", ""))
+      "| chk", hashlib.sha1(chk.encode()).hexdigest()[:12], "| tails", [e.nn_stats(d)["tail_queries"] for d in (0, 1)], "| tag", os.environ.get("TAG", ""))
