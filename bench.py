@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == f32-MFMA dense peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec peak
 FLOP_PER_PAIR = 8            # 3 sub + 1 mul + 2 fma
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def synth(n):
@@ -152,6 +152,7 @@ def main():
                     help="profiling runs: time only the `content` record's step (voxelised-surface pair, D1 + Hausdorff) and exit")
     ap.add_argument("--content-full-only", action="store_true",
                     help="profiling runs: time only the `content_full` record's step (the same pair, D1 + D2 + colour rows) and exit")
+    ap.add_argument("--content-cli-only", action="store_true", help="only the `content_cli` record (files -> report, stage by stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip full_report / cold_pair / brute / end_to_end (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying a hipGraph")
@@ -289,8 +290,78 @@ def main():
                             "the self search); matched rows come from the voxel-brick search (round 4; PCCM_VOX=0: a rebuilt grid + the "
                             "per-thread lattice kernel)"}
 
+    def content_cli_record():
+        """BASELINE configs[4]'s literal shape through the product's front door: PLY files without normals, uchar colours, one
+        reference cloud against one and against three decoded versions -- read, upload, normal estimation, minimal OBB, searches
+        and the full report (--color ycc --hausdorff --point-to-plane --normal-index neighbour), stage by stage (host clock, a
+        stream sync behind every stage).  Three rates: the reference cloud's share of the work is done once (CloudPair.with_reconst)."""
+        import tempfile
+        from open_pcc_metric_amd.io import read_point_cloud, write_point_cloud
+        ca, cb = synth_content()
+        rng = np.random.default_rng(78)
+
+        def colours(p):
+            c = np.stack([128 + 100 * np.sin(p[:, 0] / 37.0), 128 + 100 * np.cos(p[:, 1] / 23.0), 128 + 90 * np.sin(p[:, 2] / 51.0)], 1)
+            return np.clip(np.rint(c + rng.normal(0, 6, c.shape)), 0, 255).astype(np.uint8) / 255.0
+
+        decoded = [cb]
+        for step in (2, 4):
+            q = np.unique((np.round(ca / step) * step).astype(np.float32), axis=0)
+            decoded.append(np.ascontiguousarray(q[rng.random(len(q)) >= 0.03]))
+        copts = CalculateOptions(color="ycc", hausdorff=True, point_to_plane=True)
+        with tempfile.TemporaryDirectory() as tmp:
+            ref = os.path.join(tmp, "ref.ply")
+            write_point_cloud(ref, PointCloud(ca, None, colours(ca)), coord_dtype="float")
+            paths = []
+            for k, d in enumerate(decoded):
+                paths.append(os.path.join(tmp, f"dec{k}.ply"))
+                write_point_cloud(paths[-1], PointCloud(d, None, colours(d)), coord_dtype="float")
+
+            def run(paths_):
+                st = {"read": 0.0, "upload_and_searches": 0.0, "normals": 0.0, "extent": 0.0, "report": 0.0}
+                t_all = time.perf_counter()
+                t0 = time.perf_counter()
+                origin = read_point_cloud(ref)
+                st["read"] += time.perf_counter() - t0
+                pair = None
+                for pth in paths_:
+                    t0 = time.perf_counter()
+                    dec = read_point_cloud(pth)
+                    t1 = time.perf_counter()
+                    pair = CloudPair(origin, dec, device=local, nn_engine=args.engine, normal_index="neighbour") if pair is None else pair.with_reconst(dec)
+                    pair._engine.sync()
+                    t2 = time.perf_counter()
+                    pair._require_normals(0)
+                    pair._require_normals(1)
+                    pair._engine.sync()
+                    t3 = time.perf_counter()
+                    pair.get_extent()
+                    t4 = time.perf_counter()
+                    with np.errstate(divide="ignore"):
+                        text = MetricCalculator(pair).calculate(transform_options(copts)).as_df().to_string()
+                    t5 = time.perf_counter()
+                    for key, dtv in (("read", t1 - t0), ("upload_and_searches", t2 - t1), ("normals", t3 - t2), ("extent", t4 - t3), ("report", t5 - t4)):
+                        st[key] += dtv
+                pair.close()
+                total = time.perf_counter() - t_all
+                return {**{k: round(v * 1e3, 3) for k, v in st.items()}, "total_ms": round(total * 1e3, 3), "report_rows": text.count("\n")}
+
+            run(paths[:1])                                   # warm: contexts, kernels, file cache
+            one = run(paths[:1])
+            three = run(paths)
+            separate = sum(run([pth])["total_ms"] for pth in paths)
+        return {"points": [len(ca)] + [len(d) for d in decoded], "one_rate_ms": one, "three_rates_ms": three,
+                "three_separate_runs_ms": round(separate, 3),
+                "note": "PLY (binary, float xyz + uchar rgb, no normals) -> full report as text; stages in ms on the host clock with a stream sync "
+                        "behind each; three_rates = one reference cloud against three decoded clouds through CloudPair.with_reconst (the "
+                        "reference is read, uploaded, given normals, a minimal OBB and a self search once); three_separate_runs = the sum of "
+                        "three one-rate runs"}
+
     if args.content_only:
         print(json.dumps({"content": content_record(args.steps or 50)}), flush=True)
+        return
+    if args.content_cli_only:
+        print(json.dumps({"content_cli": content_cli_record()}), flush=True)
         return
     if args.content_full_only:
         print(json.dumps({"content_full": content_full_record(args.steps or 50)}), flush=True)
@@ -474,6 +545,7 @@ def main():
         # (1b) PCC-like content: voxelised surfaces take the per-thread search, not the brick kernel
         line["content"] = content_record(30)
         line["content_full"] = content_full_record(20)
+        line["content_cli"] = content_cli_record()
 
         # (2) end to end, for the record (never `value`): a FRESH pair per iteration -- upload of both clouds and their
         # normals from pageable host memory, ingest, both sweeps, the same report -- through the pooled context

@@ -15,7 +15,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpccm.so")
+# PCCM_LIB: another build of the same library (tests load a diagnostic build -- make DIAG=1 BUILD=<dir> -- through it)
+LIB_PATH = os.environ.get("PCCM_LIB") or os.path.join(_HERE, "csrc", "libpccm.so")
 
 OK, E_ARG, E_NODEV, E_HIP, E_OOM, E_STATE, E_RANGE = 0, -1, -2, -3, -4, -5, -6
 F32, F64 = 0, 1

@@ -1147,7 +1147,7 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         const double *base = stride >= 2 ? (const double *)res->rec.p : dev;
         UnitJob *host_job = nullptr;
         static const bool merge = [] {
-            const char *e = getenv("PCCM_REDUCE_MERGE");
+            const char *e = PCCM_DIAG_ENV("PCCM_REDUCE_MERGE");
             return !(e && e[0] == '0');
         }();
         if (stride >= 2 && merge)

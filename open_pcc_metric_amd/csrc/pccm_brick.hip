@@ -1,36 +1,41 @@
 // LDS-brick ring-1 search for gfx950: the dominant kernel of the default (grid) engine on fp32-exact clouds.
 //
-// Stands under get_neighbour_cloud(), open_pcc_metric/cloud_pair.py:10-42 (one search_knn_vector_3d call per
-// point there), with the D2 projection of metric.py:146-153 fused into the same pass.
+// Stands under get_neighbour_cloud(), open_pcc_metric/cloud_pair.py:10-42 (one search_knn_vector_3d call per point there).
 //
-// One workgroup owns a *brick* of the grid: BX x BY x BZ cells (BX <= 48 cells along the x-fastest axis,
-// BY = 4, BZ = 2).  Its queries are the iterating cloud's records in those cells -- eight contiguous runs of
-// the cell-sorted array -- and every candidate any of them can have in ring 1 lies in the (BX+2) x 6 x 4 cells
-// around the brick: 24 contiguous x-runs of the searched cloud's cell-sorted array.
-//   1. 24 + 8 lanes fetch the run bounds (cell_start) of the searched and the iterating cloud; two wave scans
-//      turn them into LDS offsets (every run starts on an even position: odd runs get one far-away pad record),
-//   2. the 24 runs are copied into LDS -- all global loads of the phase issued before the first LDS write -- two
-//      records per 32-byte slot, component-interleaved {x0 x1 y0 y1 z0 z1 row0 row1} (~3 staged records per query
-//      instead of 9.5 for the per-wave staging of round 1), together with their cell starts, rebased to LDS positions,
-//   3. every lane takes ONE query of the brick (the workgroup is sized to the brick's expected query count) in
-//      cell-sorted order, so the lanes of a wave sit in neighbouring cells of one x-row and their LDS reads broadcast
-//      or fall on consecutive banks; per query nine x-runs of three cells each are scanned slot by slot: two
-//      ds_read_b128, six packed-fp32 instructions for both candidates, (best, second best, address of the best)
-//      tracked per slot -- 15 VALU instructions per pair of candidates.  A slot may bring a record of a neighbouring cell
-//      along: a real point that can only lose, so no per-candidate range test exists,
-//   4. certification as in pccm_brute.hip K2 -- the fp32 winner is the unique fp64 winner when the second best
-//      d32 lies above thr(best), evaluated in fp32 with a conservative margin -- then the exact fp64 d2 from the
-//      winner's LDS record (fp32-exact inputs: (double)(float)x == x), the ring-1 stop rule, and the fused epilogue:
-//      error vector, projection on the searched cloud's normal (row i of it: reference quirk Q1, its gather issued
-//      before the scan; or row nn(i)), ONE 32-byte result record in row order.
-// Queries that are not certified (near ties) or not settled by ring 1 go to the tail list
-// (k_grid_finish -> k2b_fallback).  A brick whose 24 runs do not fit the LDS budget (clumped data) sends all
-// its queries there.
+// One workgroup owns a *brick* of the grid: BX x BY x BZ cells (BX <= 48 cells along the x-fastest axis, BY = 4, BZ = 2).  Its
+// queries are the iterating cloud's records in those cells -- eight contiguous runs of the cell-sorted array -- and every
+// candidate any of them can have in ring 1 lies in the (BX + 2) x 6 x 4 cells around the brick: 24 contiguous x-runs of the
+// searched cloud's cell-sorted array.
+//   1. 24 + 8 lanes fetch the run bounds (cell_start) of the searched and the iterating cloud; two wave scans turn them into
+//      LDS offsets (every run starts on an even position: odd runs get one far-away pad record),
+//   2. wave w copies runs w, w + 8, w + 16 into LDS -- every global load of the phase issued before the first LDS write -- as
+//      four PLANES x[PL] | y[PL] | z[PL] | row[PL] (PL a template parameter: the scan reaches the planes through the DS
+//      instructions' immediate offsets; ~3 staged records per query), together with their cell starts as LDS byte addresses,
+//   3. every lane takes ONE query of the brick (the workgroup is sized to the brick's expected query count) in cell-sorted
+//      order; per query nine x-runs of three cells each are scanned a PAIR of candidates per trip: three ds_read_b64 off one
+//      address register, six packed-fp32 instructions for both candidates, the nearer of the two into (best, second best,
+//      address of the best pair) -- 13 VALU instructions per pair.  The reads are software-pipelined (round 4): the next pair's
+//      are issued as soon as this pair's coordinates have been consumed.  A pair may bring a record of a neighbouring cell
+//      along: a real point that can only lose or be rejected by the stop rule, so no per-candidate range test exists,
+//   4. certification as in pccm_brute.hip K2 -- the fp32 winner is the unique fp64 winner when the second best d32 (and the
+//      winner's partner in its pair) lies above thr(best) -- the ring-1 stop rule in fp32 (never more permissive than the fp64
+//      one), and ONE 16-byte store per query: the matched record itself {x, y, z, row} (NNOut::layout 1; distance and
+//      row-indexed projection are formed by the reduction that reads the records, pccm_point.hip).  Pairs that need the
+//      projection on the neighbour's normal keep round 2's epilogue ({d2, projection[, row]} records, normal gathered here).
+// Queries that are not certified (near ties) or not settled by ring 1 go to the tail list (k_grid_tail: rings 2-3, then the
+// exact rescan, one launch).  A brick whose 24 runs do not fit the LDS budget (clumped data) sends all its queries there.
 //
-// Bound: memory latency and the scattered row-order result stores, not arithmetic -- ablations at 1M vs 1M points
-// (PCCM_BRICK_ABLATE, timing-only builds): empty launch 6 us, + run bounds and first barrier 5, + query fetch, pad
-// writes, second barrier and per-query set-up 26, + cell-start loads 10, + record loads and the scan 35, + fp64
-// epilogue, normal gather and result stores 24 = 104 us.  Reported against HBM as the contract asks.
+// What bounds it (round 4, PMC busy counters of the launch at 1M + 1M points, profiles/r04): instruction throughput, spread
+// over all pipes rather than sitting in one -- per wave 930 VALU (SQ_ACTIVE_INST_VALU = one quad-cycle each: 67 % of the
+// launch per SIMD if a vector instruction held its SIMD for four clocks, 43 % at the guide's two clocks for plain and four for
+// packed ones), 506 SALU + 123 branches (48 % of the CU's scalar issue), 176 LDS; waves are parked in s_waitcnt / barriers
+// 45 % of their cycles and ready-but-not-issued 29 %.  Experiments that moved the time: fewer instructions (round 3, in
+// proportion), software-pipelined LDS reads (-5 %); experiments that did not: spreading the first workgroups of a CU over a
+// workgroup's lifetime (s_sleep stagger: +0..4 us), two pairs per trip (27 instead of 38 issue slots per four candidates: +-0),
+// resident workgroups with the next brick's loads in flight under the scan (scripts/attic/pccm_bstream.hip.txt: 83 against 70 us
+// -- 26 more registers cost a workgroup per CU and the per-brick instructions stay).  The time is 41 us + 7.7 ns per workgroup
+// over bricks of 16 / 23 / 30 / 45 cells: per-brick set-up (run bounds, staging, window bounds, epilogue: 39 % of the vector
+// instructions) is what a shorter kernel has to remove.  Reported against HBM as the contract asks.
 // Neighbouring bricks share runs through the XCD's L2 (XCD-aware brick order, as in round 1).
 #include "pccm_brick.h"
 
@@ -619,7 +624,7 @@ static void launch_plane(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
         return;
     }
 #endif
-    static const bool v_free = [] { const char *e = getenv("PCCM_BRICK_V64"); return e && e[0] == '0'; }();
+    static const bool v_free = [] { const char *e = PCCM_DIAG_ENV("PCCM_BRICK_V64"); return e && e[0] == '0'; }();
     if (v_free && !self) {     // A/B: no register cap
         hipLaunchKernelGGL((k_brick_query_free<BY, BZ, PL>), grid, dim3(nt), lds, ctx->stream, jobs, g, bp);
         return;
@@ -663,7 +668,7 @@ static void launch_shape(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g
 int launch_brick_query(pccm_ctx *ctx, const QueryJobs &jobs, const GridGeom &g, bool self)
 {
     BrickParams bp;
-    static const int bx_env = [] { const char *e = getenv("PCCM_BRICK_BX"); return e ? atoi(e) : 0; }();
+    static const int bx_env = [] { const char *e = PCCM_DIAG_ENV("PCCM_BRICK_BX"); return e ? atoi(e) : 0; }();
     const int bx_max = bx_env > 0 ? bx_env : 48;          // bricks of <= 48 cells: ~65 records per staged run at 1.4 points per cell
     const int nbx = (g.dim[0] + bx_max - 1) / bx_max;
     bp.bx = (g.dim[0] + nbx - 1) / nbx;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k2b_fallback(RescanJobs jobs)
 static int scan_qt()
 {
     static int qt = [] {
-        const char *e = getenv("PCCM_SCAN_QT");
+        const char *e = PCCM_DIAG_ENV("PCCM_SCAN_QT");
         int v = e ? atoi(e) : 8;
         return (v == 4 || v == 8) ? v : 8;
     }();

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void k_grid_query(QueryJobs jobs, GridGeom g)
 static double points_per_cell()
 {
     static double k = [] {
-        const char *e = getenv("PCCM_GRID_PPC");
+        const char *e = PCCM_DIAG_ENV("PCCM_GRID_PPC");
         // 1.4 points per cell: per step at 1M / 4M / 8M points 0.250 / 0.763 / 1.627 ms (1.5: 0.252 / 0.768 / 1.634; 1.3: 0.251 / 0.822 /
         // 1.639; 1.2: 0.253 / 0.803 / 1.825 -- fewer candidates per query, but more tails and more cell starts)
         double v = e ? atof(e) : 1.4;
@@ -897,7 +897,7 @@ static int decide_scale(pccm_ctx *ctx, uint64_t key)
     if (c.n > 0) {
         Occupancy o;
         int rc;
-        if (!getenv("PCCM_GRID_NO_TRIM")) {        // first, so that no histogram is ever built over a blown-up box
+        if (!PCCM_DIAG_ENV("PCCM_GRID_NO_TRIM")) {        // first, so that no histogram is ever built over a blown-up box
             bool changed = false;
             if ((rc = trim_box(ctx, changed))) return rc;
         }
@@ -1093,6 +1093,15 @@ static int ensure_grid(pccm_ctx *ctx, bool need64 = false, int need_mask = 3, ui
         shard->done = true;
     }
     if (jobs.total > 0 && (rc = sort_by_cell(ctx, jobs, g, ncells, first, rec32, zero, nzero))) return rc;
+#ifdef PCCM_DIAG
+    // diagnostic builds only (tests/test_gpu_device_errors.py): a cell start that contradicts the records, so that the brick
+    // build meets records outside its tile -- the state pccm_vox.hip reports through the device error word
+    if (vox && jobs.total > 0 && getenv("PCCM_DIAG_CORRUPT_CS") && ncells > 200) {
+        const uint32_t bad = (uint32_t)ctx->cloud[0].n;
+        PCCM_HIP(hipMemcpyAsync(cs + 128, &bad, sizeof(bad), hipMemcpyHostToDevice, ctx->stream));
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+#endif
     if (vox && jobs.total > 0) {                           // bricks of the clouds just built
         VoxBuild vb;
         vb.njobs = 0;
@@ -1542,6 +1551,7 @@ struct TieJob {
     const void *srecs;          // cell-sorted records of the searched cloud
     const uint32_t *cs;         // ... its cell starts
     const double *q64;          // iterating cloud, fp64 rows
+    const double *s64;          // searched cloud, fp64 rows (the pick's coordinates when its ball is not enumerated)
     const double *nrm;          // searched cloud's normals, or null (counts only)
     const int32_t *idx;         // shard's matched rows
     const double *d2;           // ... and squared distances
@@ -1596,10 +1606,9 @@ __global__ __launch_bounds__(256) void k_tie_exposure(TieJob J, GridGeom g, doub
                     }
                 }
         }
-        if (mult == 0) {                       // skipped, or the winner came from beyond the grid (rescan): the pick alone
-            const int64_t k = (J.normal_mode == PCCM_NORMAL_ROW) ? row : (int64_t)pick;
-            (void)k;
-            vmin = vmax = vpick = 0.0;
+        if (mult == 0) {                       // skipped, or the winner came from beyond the grid (rescan): the pick alone counts,
+            const double *r = J.s64 + 3 * (int64_t)pick;      // with its own squared projection (the interval stays an interval)
+            vmin = vmax = vpick = value(r[0], r[1], r[2], pick);
             mult = 1;
             skipped = 1;
         }
@@ -1661,6 +1670,7 @@ int tie_exposure(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, const
     J.srecs = (const char *)gr.recs.p + (size_t)(si ? gr.n[0] : 0) * (gr.rec32 ? sizeof(Rec32) : sizeof(GridRec));
     J.cs = (const uint32_t *)gr.cell_start.p + (si ? gr.ncells + 1 : 0);
     J.q64 = it.xyz64;
+    J.s64 = se.xyz64;
     J.nrm = normal_mode >= 0 ? se.nrm64 : nullptr;
     J.idx = res.idx;
     J.d2 = res.d2;

@@ -542,7 +542,7 @@ int sort_by_cell(pccm_ctx *ctx, const BuildJobs &jobs, const GridGeom &g, int64_
         for (int k = 0; k < jobs.njobs; ++k) nmax = jobs.j[k].n > nmax ? jobs.j[k].n : nmax;
         while (P.lg > 6 && (double)nmax * (double)(1ll << P.lg) / (double)ncells > 2000.0 && ((ncells >> (P.lg - 1)) + 1) <= 8192) --P.lg;
     }
-    static const int lg_env = [] { const char *e = getenv("PCCM_BUILD_LG"); return e ? atoi(e) : 0; }();
+    static const int lg_env = [] { const char *e = PCCM_DIAG_ENV("PCCM_BUILD_LG"); return e ? atoi(e) : 0; }();
     if (lg_env >= 8 && lg_env <= kMaxLg && (ncells >> lg_env) < 8192) P.lg = lg_env;
     P.nbin = (int)((ncells + (1ll << P.lg) - 1) >> P.lg);
     if (P.nbin > 8192) return fail(PCCM_E_ARG, "grid of %lld cells is too large", (long long)ncells);

@@ -8,6 +8,15 @@
 
 #include "pccm.h"
 
+// A/B switches that no test of the shipped library uses (brick length, register cap, build bins, cells per point, ...) exist in
+// diagnostic builds only (make DIAG=1): the product reads the environment for the switches tests/test_gpu_ab_paths.py exercises
+// and for nothing else.
+#ifdef PCCM_DIAG
+#define PCCM_DIAG_ENV(name) getenv(name)
+#else
+#define PCCM_DIAG_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 namespace pccm {
 
 // ---- geometry of the brute-force scan (K1) ------------------------------------------

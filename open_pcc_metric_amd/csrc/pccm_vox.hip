@@ -228,7 +228,9 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
             s_cs[lane] = J.qcs[c + (uint32_t)(lane - 36)];
         }
         __syncthreads();
-        const uint32_t q0 = s_cs[36], nq = s_cs[37] - q0;
+        // (cell starts never decrease; one that does -- memory the build did not write -- must not become a count of 4 billion queries)
+        const uint32_t q0 = s_cs[36], nq = s_cs[37] >= s_cs[36] ? s_cs[37] - s_cs[36] : 0u;
+        if (s_cs[37] < s_cs[36] && lane == 0 && jobs.err) atomicOr(jobs.err, kErrVoxState);
         // ---- 2. bricks (a quarter-brick per lane and pass) and the first 64 queries, all in flight together -----------------
 #pragma unroll
         for (int u = 0; u < 2; ++u) {

@@ -73,3 +73,22 @@ def test_tie_free_data_collapses_the_interval():
             assert t["d2_mse_min"] == t["d2_mse_max"] == t["d2_mse_pick"]
         counts_only = pair.tie_exposure(True, point_to_plane=False)
         assert counts_only["tied_queries"] == 0 and "d2_mse_min" not in counts_only
+
+
+def test_far_outliers_count_with_their_own_projection():
+    """Queries whose ball is not enumerated (far outliers: more than 4096 cells, or a winner found by the exact rescan) enter all
+    three sums with the library's own pick, so that d2_mse_pick is the reported GeoMSE(point_to_plane=True) and the interval
+    still contains it."""
+    import open_pcc_metric_amd.metric as m
+    from open_pcc_metric_amd.calculator import MetricCalculator
+    rng = np.random.default_rng(8)
+    n = 30000
+    a, b = rng.random((n, 3), dtype=np.float32), rng.random((n, 3), dtype=np.float32)
+    a[:25] += np.float32(40.0) * rng.standard_normal((25, 3)).astype(np.float32)       # strays far from everything
+    na, nb = rng.standard_normal((n, 3)).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32)
+    with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], nn_engine="grid") as pair:
+        t = pair.tie_exposure(True, point_to_plane=True)
+        mse = float(MetricCalculator(pair).calculate([m.GeoMSE(True, True)]).as_dict()[("GeoMSE", True, True)])
+        assert t["not_enumerated"] > 0
+        assert np.isclose(t["d2_mse_pick"], mse, rtol=1e-11, atol=0)
+        assert t["d2_mse_min"] <= mse * (1 + 1e-12) and mse <= t["d2_mse_max"] * (1 + 1e-12)
