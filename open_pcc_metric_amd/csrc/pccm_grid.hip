@@ -597,14 +597,14 @@ static bool use_coop(const pccm_ctx *ctx)
 // One geometry for BOTH clouds (union bounding box, cell edge from the mean point count): a query's
 // cell in the searched cloud's grid is then the cell it was sorted into in its own cloud's grid, which is
 // what lets the cooperative kernel work on runs of consecutive cells.
-static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells, double h_scale, bool vox = false)
-{
+static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells, double h_scale, bool vox = false, int solo = -1)
+{   // solo >= 0: a grid over that cloud alone (its own box and count: estimate_normals), never trimmed
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     double npts = 0.0;
     int nset = 0;
     for (int k = 0; k < 2; ++k) {
         const Cloud &c = ctx->cloud[k];
-        if (c.n <= 0) continue;
+        if (c.n <= 0 || (solo >= 0 && k != solo)) continue;
         for (int a = 0; a < 3; ++a) {
             lo[a] = c.bb_min[a] < lo[a] ? c.bb_min[a] : lo[a];
             hi[a] = c.bb_max[a] > hi[a] ? c.bb_max[a] : hi[a];
@@ -612,7 +612,7 @@ static void choose_geometry(const pccm_ctx *ctx, GridGeom &g, int64_t &ncells, d
         npts += (double)c.n;
         ++nset;
     }
-    if (ctx->grid.boxed)                 // outliers trimmed away (decide_geometry): they clamp into the boundary cells
+    if (ctx->grid.boxed && solo < 0)     // outliers trimmed away (decide_geometry): they clamp into the boundary cells
         for (int a = 0; a < 3; ++a) {
             lo[a] = ctx->grid.box_lo[a];
             hi[a] = ctx->grid.box_hi[a];
@@ -743,11 +743,11 @@ struct Occupancy {
     int64_t ncells = 0;
 };
 
-static int measure_occupancy(pccm_ctx *ctx, const Cloud &c, double scale, Occupancy &o)
+static int measure_occupancy(pccm_ctx *ctx, const Cloud &c, double scale, Occupancy &o, int solo = -1)
 {
     GridGeom g;
     int64_t ncells;
-    choose_geometry(ctx, g, ncells, scale);
+    choose_geometry(ctx, g, ncells, scale, false, solo);
     int rc;
     if ((rc = ensure(ctx, ctx->g_hist, (size_t)(ncells + 1) * sizeof(uint32_t)))) return rc;
     uint32_t *hist = (uint32_t *)ctx->g_hist.p;
@@ -771,7 +771,7 @@ static int measure_occupancy(pccm_ctx *ctx, const Cloud &c, double scale, Occupa
 // which is what a query pays for: scanner data is sparse far out and crowded near the sensor, so its plain mean
 // looks harmless (4) while the typical point shares its cell with 50 others.  A step that does not relieve the
 // crowding (duplicates: identical points cannot be separated) is taken back.
-static int fit_scale(pccm_ctx *ctx, const Cloud &c, double &scale, Occupancy &o)
+static int fit_scale(pccm_ctx *ctx, const Cloud &c, double &scale, Occupancy &o, int solo = -1)
 {
     const double target = 2.0 * points_per_cell(), target_sb = 4.0 * points_per_cell();
     auto crowding = [&](const Occupancy &q) { return fmax(q.mean / target, q.sb / target_sb); };
@@ -779,7 +779,7 @@ static int fit_scale(pccm_ctx *ctx, const Cloud &c, double &scale, Occupancy &o)
     Occupancy prev;
     double prev_scale = 1.0;
     for (int it = 0; it < 4; ++it) {
-        int rc = measure_occupancy(ctx, c, scale, o);
+        int rc = measure_occupancy(ctx, c, scale, o, solo);
         if (rc) return rc;
         if (it > 0 && crowding(o) > 0.8 * crowding(prev)) {      // no relief: keep the coarser (cheaper) grid
             scale = prev_scale;
@@ -790,7 +790,7 @@ static int fit_scale(pccm_ctx *ctx, const Cloud &c, double &scale, Occupancy &o)
         GridGeom g2;
         int64_t nc2;
         const double next = scale * fmax(0.35, pow(1.0 / crowding(o), 1.0 / 2.4));
-        choose_geometry(ctx, g2, nc2, next);
+        choose_geometry(ctx, g2, nc2, next, false, solo);
         if (nc2 == o.ncells) break;                // cell budget or per-axis limit reached
         prev = o;
         prev_scale = scale;
@@ -1698,6 +1698,55 @@ int tie_exposure(pccm_ctx *ctx, int dir, const Cloud &it, const Cloud &se, const
     out[4] = h[2];
     out[5] = (double)c[2];
     out[6] = (double)c[3];
+    return PCCM_OK;
+}
+
+// A grid over ONE cloud with cells sized for that cloud (GridRec records: pccm_normals.hip): the pair's geometry follows its
+// larger cloud, and a decoded cloud of a fifteenth of the reference's points -- a low rate of BASELINE configs[4] -- had its
+// k = 30 neighbourhoods spread over six rings of such cells (43 ms of normal estimation for 59 000 points, round 4).
+// The cell-edge factor is cached with the cloud; the pair's grid is gone afterwards (the next search builds it again).
+int grid_ensure_solo(pccm_ctx *ctx, int which)
+{
+    Grid &gr = ctx->grid;
+    Cloud &c = ctx->cloud[which];
+    if (ctx->capturing) {
+        ctx->capture_failed = true;
+        return fail(PCCM_E_STATE, "normal estimation is not allowed during graph capture");
+    }
+    int rc;
+    if (c.solo_scale_version != c.version) {
+        Occupancy o;
+        double scale = 1.0;
+        if ((rc = fit_scale(ctx, c, scale, o, which))) return rc;
+        c.solo_scale = scale;
+        c.solo_scale_version = c.version;
+    }
+    ProfScope ps(ctx, PCCM_K_GRID_BUILD);
+    GridGeom g;
+    int64_t ncells;
+    choose_geometry(ctx, g, ncells, c.solo_scale, false, which);
+    const int64_t n0 = ctx->cloud[0].n, n1 = ctx->cloud[1].n;
+    if ((rc = ensure(ctx, gr.cell_start, (size_t)2 * (ncells + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, gr.recs, (size_t)(n0 + n1 > 0 ? n0 + n1 : 1) * sizeof(GridRec)))) return rc;
+    BuildJobs jobs;
+    jobs.njobs = 1;
+    jobs.total = c.n;
+    jobs.j[0] = {c.xyz64, (const float *)c.xyz32, 0, c.n, (uint32_t *)gr.cell_start.p + (size_t)which * (ncells + 1)};
+    jobs.j[1] = jobs.j[0];
+    if ((rc = sort_by_cell(ctx, jobs, g, ncells, (char *)gr.recs.p + (size_t)(which ? n0 : 0) * sizeof(GridRec), false))) return rc;
+    for (int a = 0; a < 3; ++a) {
+        gr.dim[a] = g.dim[a];
+        gr.org[a] = g.org[a];
+        gr.h[a] = g.h[a];
+        gr.inv_h[a] = g.inv_h[a];
+    }
+    gr.ncells = ncells;
+    gr.n[0] = n0;
+    gr.n[1] = n1;
+    gr.key = 0;                                            // not the pair's grid: whoever searches next builds that
+    gr.rec32 = false;
+    gr.lattice = gr.vox = gr.vox_rows = false;
+    gr.built = 0;
     return PCCM_OK;
 }
 

@@ -69,6 +69,8 @@ struct Cloud {
     double maxabs = 0.0;
     double bb_min[3] = {0, 0, 0}, bb_max[3] = {0, 0, 0};   // bounding box (fp64 coordinates)
     uint64_t version = 0;       // bumped by pccm_set_cloud (grid caches key on it)
+    double solo_scale = 1.0;    // cell-edge factor of a grid over this cloud alone (grid_ensure_solo), decided for ...
+    uint64_t solo_scale_version = ~0ull;   // ... this version of the cloud
 };
 
 struct DevBuf {
@@ -280,7 +282,8 @@ int nn_brute(pccm_ctx *ctx, const Cloud &it, const Cloud &se, bool self, NNResul
 int nn_grid(pccm_ctx *ctx, int ndirs, const int *dirs, int force_idx = 0);   // force_idx: records carry the matched row whatever pccm_nn_want_idx says
 void grid_release(pccm_ctx *ctx);
 void grid_invalidate(pccm_ctx *ctx);
-int grid_ensure(pccm_ctx *ctx, bool need64 = false, int need_mask = 3);   // need64: GridRec records wanted (pccm_normals.hip reads them)
+int grid_ensure(pccm_ctx *ctx, bool need64 = false, int need_mask = 3);
+int grid_ensure_solo(pccm_ctx *ctx, int which);    // GridRec grid over cloud `which` alone, cells sized for it (normal estimation)   // need64: GridRec records wanted (pccm_normals.hip reads them)
 int spatial_order(pccm_ctx *ctx, Cloud &c);      // fills Cloud::sp (ingest; no-op for clouds that are not fp32-exact)
 int grid_decide(pccm_ctx *ctx, bool *hostile);   // geometry decision for the current pair (cached per pair)
 int grid_prefers_brute(pccm_ctx *ctx, bool *yes); // builds the grid if needed; isolation verdict (cached per pair)

@@ -417,7 +417,13 @@ int estimate_normals(pccm_ctx *ctx, int which, int k)
     if (c.n <= 0) return fail(PCCM_E_STATE, "cloud %d is not set", which);
     if (k < 3 || k > kKnnMax) return fail(PCCM_E_ARG, "k must be in 3..%d", kKnnMax);
     int rc;
-    if ((rc = grid_ensure(ctx, true, 1 << which))) return rc;      // this file reads GridRec (fp64) records of one cloud
+    // GridRec (fp64) records of this cloud alone.  The pair's geometry follows the pair's larger cloud: fine for that cloud and for
+    // one of similar size, hopeless for a much sparser one (a low rate of a codec: k = 30 neighbours then lie six rings out), which
+    // gets cells of its own (grid_ensure_solo: a few histogram passes, cached with the cloud)
+    const Cloud &other = ctx->cloud[1 - which];
+    if (other.n > 2 * c.n) {
+        if ((rc = grid_ensure_solo(ctx, which))) return rc;
+    } else if ((rc = grid_ensure(ctx, true, 1 << which))) return rc;
     const Grid &gr = ctx->grid;
     KnnGeom g;
     for (int a = 0; a < 3; ++a) {
