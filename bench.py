@@ -481,10 +481,13 @@ def main():
                     "kernel": "k_brick_query (ring-1 search of both directions, one launch; results = matched records)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": gq_n, "algorithmic_bytes_per_launch": alg_bytes,
                     "compulsory_bytes_per_launch": compulsory, "traffic_note": traffic_note,
-                    "arithmetic": "fp32 candidate filter in LDS (packed fp32, 13 VALU instructions per pair of candidates), fp32 stop rule",
-                    "limiter": "vector-ALU issue, not HBM: PMC (profiles/r03) counts ~930 VALU instructions per wave, 33 120 waves -> "
-                               "~120 k issue clocks per SIMD of the launch's ~150-170 k; more workgroups per CU, conflict-free LDS reads "
-                               "and fewer memory round trips each left the time unchanged, fewer instructions shortened it in proportion"}
+                    "arithmetic": "fp32 candidate filter in LDS (packed fp32, 13 VALU instructions per pair of candidates, LDS reads software-pipelined), fp32 stop rule",
+                    "limiter": "priced against HBM as the contract prescribes, but not bound by it (1.5 of 8 TB/s): PMC busy counters "
+                               "(profiles/r04/grid_1M_busy_counters.json) show instruction throughput spread over all pipes -- per wave 930 VALU "
+                               "(67 % of the launch per SIMD at four clocks each, 43 % at the guide's two / four), 506 SALU + 123 branches, 176 LDS; "
+                               "waves parked 45 % of their cycles, ready-but-unissued 29 %; time = 41 us + 7.7 ns per workgroup over brick sizes "
+                               "(per-brick set-up is 39 % of the vector instructions); pipelined LDS reads -5 %, staggered starts / two pairs per "
+                               "trip / resident workgroups with prefetch: no gain (DESIGN.md section 3)"}
 
     reduce_roofline = None
     red_ms, red_n = eng.profile_get("reduce")
