@@ -288,6 +288,16 @@ def _as_rows(a, what: str) -> Tuple[object, int, int, int, object]:
     return arr.ctypes.data_as(ctypes.c_void_p), int(arr.shape[0]), F32 if arr.dtype == np.float32 else F64, 0, arr
 
 
+def _modes(normal_mode, k: int):
+    """One normal mode for all k requests, or one per request."""
+    if isinstance(normal_mode, str):
+        return [NORMAL_MODES[normal_mode]] * k
+    modes = [NORMAL_MODES[m] for m in normal_mode]
+    if len(modes) != k:
+        raise ValueError(f"{len(modes)} normal modes for {k} requests")
+    return modes
+
+
 class Engine:
     """One libpccm context = one GPU.  Method names mirror include/pccm.h."""
     keeps_self_search = True      # pccm_set_cloud(1, ...) leaves cloud 0 and its self search untouched (CloudPair.with_reconst)
@@ -499,7 +509,7 @@ class Engine:
         arr = ctypes.c_int * k
         dirs = arr(*[int(r[0]) for r in requests])
         mets = arr(*[int(r[1]) for r in requests])
-        modes = arr(*([NORMAL_MODES[normal_mode]] * k))
+        modes = arr(*_modes(normal_mode, k))
         _check(self._lib.pccm_reduce_prefetch_many(self._ctx, k, dirs, mets, modes))
 
     def reduce(self, direction: int, metric: int, normal_mode: str = "row"):
@@ -524,7 +534,7 @@ class Engine:
         arr = ctypes.c_int * k
         out = (ctypes.c_double * (3 * k))()
         _check(self._lib.pccm_reduce_total_many(self._ctx, k, arr(*[int(r[0]) for r in requests]), arr(*[int(r[1]) for r in requests]),
-                                                arr(*([NORMAL_MODES[normal_mode]] * k)), out))
+                                                arr(*_modes(normal_mode, k)), out))
         return [(np.float64(out[3 * i]), np.float64(out[3 * i + 1]), np.float64(out[3 * i + 2])) for i in range(k)]
 
     def reduce_chunks_many(self, requests, normal_mode: str = "row"):

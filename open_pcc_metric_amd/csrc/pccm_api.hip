@@ -329,7 +329,7 @@ int pccm_ctx_create(int device, void *hip_stream, pccm_ctx **out)
     }
     if (!rc) *ctx->host_err = 0u;
     if (!rc && hipEventCreateWithFlags(&ctx->batch_ev, hipEventDisableTiming) != hipSuccess) rc = fail(PCCM_E_HIP, "hipEventCreate failed");
-    if (!rc) rc = ensure(ctx, ctx->stats, 16 * sizeof(unsigned long long));      // [0..9] the main stream's scratch, [12..14] the copy stream's
+    if (!rc) rc = ensure(ctx, ctx->stats, 32 * sizeof(unsigned long long));      // [0..9] the main stream's scratch, [12..14] the copy stream's, [16..22] colour reduction of the other direction
     if (!rc && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = fail(PCCM_E_HIP, "hipMemsetAsync failed");
     if (rc) {
@@ -501,6 +501,7 @@ int pccm_set_colors(pccm_ctx *ctx, int which, const void *rgb, int64_t n, int dt
     if (n != c.n) return fail(PCCM_E_ARG, "cloud %d has %lld points but %lld colours", which, (long long)c.n, (long long)n);
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     c.n_rgb = 0;
+    ctx->rgb_gen++;
     int rc = grow((void **)&c.rgb64, c.cap_rgb, (size_t)n * 3 * sizeof(double));
     if (rc) return rc;
     const void *dsrc = nullptr;
@@ -526,6 +527,7 @@ int pccm_set_colors_u8(pccm_ctx *ctx, int which, const unsigned char *rgb, int64
     if (n != c.n) return fail(PCCM_E_ARG, "cloud %d has %lld points but %lld colours", which, (long long)c.n, (long long)n);
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     c.n_rgb = 0;
+    ctx->rgb_gen++;
     int rc = grow((void **)&c.rgb64, c.cap_rgb, (size_t)n * 3 * sizeof(double));
     if (rc) return rc;
     const void *dsrc = nullptr;
@@ -572,27 +574,58 @@ int pccm_color_reduce(pccm_ctx *ctx, int dir, int scheme, double scale, const in
     CHECK_CTX(ctx);
     NOT_CAPTURING(ctx);
     if (!sum_out || !max_out) return fail(PCCM_E_ARG, "null output");
-    const Cloud *own, *other;
-    const int32_t *drows;
-    int rc = color_operands(ctx, dir, scheme, rows, nrows, &own, &other, &drows);
+    const Cloud *own[2], *other[2];
+    const int32_t *drows[2];
+    int rc = color_operands(ctx, dir, scheme, rows, nrows, &own[0], &other[0], &drows[0]);
     if (rc) return rc;
-    const int64_t n = own->n;
-    rc = ensure(ctx, ctx->color_cols, (size_t)n * 3 * sizeof(double));
+    pccm_ctx::ColorMemo &memo = ctx->color_memo;
+    if (!rows && memo.valid && memo.dir == dir && memo.scheme == scheme && memo.scale == scale && memo.gen == ctx->nn_gen[dir] &&
+        memo.rgb_gen == ctx->rgb_gen) {
+        memo.valid = false;                               // (answered once: the host side keeps what it was given)
+        if (memo.range_bad) return fail(PCCM_E_RANGE, "a neighbour row is outside the other cloud");
+        memcpy(max_out, memo.max, sizeof(memo.max));
+        memcpy(sum_out, memo.sum, sizeof(memo.sum));
+        return PCCM_OK;
+    }
+    memo.valid = false;
+    // the other direction rides along when it could be asked for the same way: the pair's own rows, an unsharded result
+    int njobs = 1;
+    const int sib = dir == PCCM_DIR_LEFT ? PCCM_DIR_RIGHT : PCCM_DIR_LEFT;
+    if (!rows && ctx->nn[sib].valid && ctx->nn[sib].begin == 0 && ctx->nn[sib].end == ctx->cloud[sib == PCCM_DIR_LEFT ? 0 : 1].n &&
+        color_operands(ctx, sib, scheme, nullptr, 0, &own[1], &other[1], &drows[1]) == PCCM_OK)
+        njobs = 2;
+    const int64_t n[2] = {own[0]->n, njobs == 2 ? own[1]->n : 0};
+    rc = ensure(ctx, ctx->color_cols, (size_t)(n[0] + n[1]) * 3 * sizeof(double));
     if (rc) return rc;
-    // stats scratch: [0..2] column maxima as bit keys, [3..5] column sums, [6] range flag
-    unsigned long long *small = (unsigned long long *)ctx->stats.p;
-    PCCM_HIP(hipMemsetAsync(small, 0, 7 * sizeof(unsigned long long), ctx->stream));
-    rc = launch_color_rows(ctx, own->rgb64, other->rgb64, drows, n, other->n, scheme, scale, 4, (double *)ctx->color_cols.p,
-                           small, (unsigned int *)(small + 6));
+    // stats scratch per job: [0..2] column maxima as bit keys, [3..5] column sums, [6] range flag; the second job at word 16
+    unsigned long long *small[2] = {(unsigned long long *)ctx->stats.p, (unsigned long long *)ctx->stats.p + 16};
+    const double *cols[2] = {(const double *)ctx->color_cols.p, (const double *)ctx->color_cols.p + 3 * n[0]};
+    double *sums[2] = {(double *)(small[0] + 3), (double *)(small[1] + 3)};
+    for (int k = 0; k < njobs; ++k) {
+        PCCM_HIP(hipMemsetAsync(small[k], 0, 7 * sizeof(unsigned long long), ctx->stream));
+        rc = launch_color_rows(ctx, own[k]->rgb64, other[k]->rgb64, drows[k], n[k], other[k]->n, scheme, scale, 4, (double *)cols[k], small[k],
+                               (unsigned int *)(small[k] + 6));
+        if (rc) return rc;
+    }
+    rc = launch_color_colsums(ctx, njobs, cols, n, sums);
     if (rc) return rc;
-    rc = launch_color_colsum(ctx, (const double *)ctx->color_cols.p, n, (double *)(small + 3));
-    if (rc) return rc;
-    unsigned long long h[7];
-    PCCM_HIP(hipMemcpyAsync(h, small, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long h[2][7];
+    for (int k = 0; k < njobs; ++k) PCCM_HIP(hipMemcpyAsync(h[k], small[k], sizeof(h[k]), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    if (h[6]) return fail(PCCM_E_RANGE, "a neighbour row is outside the other cloud");
-    memcpy(max_out, h, 3 * sizeof(double));
-    memcpy(sum_out, h + 3, 3 * sizeof(double));
+    if (njobs == 2) {
+        memo.valid = true;
+        memo.range_bad = h[1][6] != 0;
+        memo.dir = sib;
+        memo.scheme = scheme;
+        memo.scale = scale;
+        memo.gen = ctx->nn_gen[sib];
+        memo.rgb_gen = ctx->rgb_gen;
+        memcpy(memo.max, h[1], sizeof(memo.max));
+        memcpy(memo.sum, h[1] + 3, sizeof(memo.sum));
+    }
+    if (h[0][6]) return fail(PCCM_E_RANGE, "a neighbour row is outside the other cloud");
+    memcpy(max_out, h[0], 3 * sizeof(double));
+    memcpy(sum_out, h[0] + 3, 3 * sizeof(double));
     return PCCM_OK;
 }
 
@@ -1095,11 +1128,14 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         if (metric != PCCM_METRIC_D2 && metric != PCCM_METRIC_PROJ) return fail(PCCM_E_ARG, "bad metric %d", metric);
         if (dir == PCCM_DIR_SELF) return fail(PCCM_E_ARG, "point-to-plane is not defined for the self search");
         if ((rc = check_normals(ctx, *it, *se, *res, normal_mode))) return rc;
-        if (res->rec_valid && !res->no_rows && (res->fused_mode == normal_mode || (res->rec_layout == 1 && normal_mode == PCCM_NORMAL_ROW))) {
+        if (res->rec_valid && !res->no_rows &&
+            (res->fused_mode == normal_mode || (res->rec_layout == 1 && (normal_mode == PCCM_NORMAL_ROW || normal_mode == PCCM_NORMAL_NEIGHBOUR)))) {
             dev = (const double *)res->rec.p + 1;
             stride = res->rec_stride;
             square = metric == PCCM_METRIC_D2 ? 1 : 0;       // metric.py:179: the square of the stored projection
-            if (res->rec_layout == 1) defer = se->nrm_exact32 ? 1 : 2;   // ... which this reduction forms itself (NNOut::layout)
+            // ... which this reduction forms itself from a matched record (NNOut::layout): with the normal of the query's row
+            // (streamed) or of the matched row the record carries (gathered: what a separate point pass would gather too)
+            if (res->rec_layout == 1) defer = (se->nrm_exact32 ? 1 : 2) + (normal_mode == PCCM_NORMAL_NEIGHBOUR ? 3 : 0);
         } else {
             if ((rc = ensure_plain(ctx, *res))) return rc;
             if ((rc = ensure(ctx, s.val, (size_t)(ns > 0 ? ns : 1) * sizeof(double)))) return rc;
@@ -1152,16 +1188,18 @@ static int slot_prepare(pccm_ctx *ctx, ReduceSlot &s, int dir, int metric, int n
         }();
         if (stride >= 2 && merge)
             for (int k = 0; k < uj.njobs; ++k)
-                if (uj.j[k].stride >= 2 && uj.j[k].val == base && uj.j[k].ncols == 1) host_job = &uj.j[k];
+                if (uj.j[k].stride >= 2 && uj.j[k].val == base && uj.j[k].ncols == 1 &&
+                    (uj.j[k].defer == defer || uj.j[k].defer == 3 || defer == 3))      // (one normal per job: row- and neighbour-indexed D2 do not share one)
+                    host_job = &uj.j[k];
         if (host_job) {
             host_job->c[1] = col;
             host_job->ncols = 2;
-            if (defer && (host_job->defer == 0 || host_job->defer == 3)) host_job->defer = defer;   // (3: distances only so far)
+            if (defer && defer != 3 && (host_job->defer == 0 || host_job->defer == 3)) host_job->defer = defer;   // (3: distances only so far)
         } else {
             if (uj.njobs >= 8) return fail(PCCM_E_ARG, "too many columns in one reduction batch");
             UnitJob &U = uj.j[uj.njobs];
             U.val = base; U.stride = stride; U.ncols = 1;
-            U.defer = defer; U.nrm64 = se->nrm64; U.nrm32 = se->nrm32; U.q32 = it->xyz32r; U.row0 = res->begin;
+            U.defer = defer; U.nrm64 = se->nrm64; U.nrm32 = se->nrm32; U.nrm_rows = se->n_nrm; U.q32 = it->xyz32r; U.row0 = res->begin;
             U.c[0] = col; U.c[1] = col;
             U.ns = ns; U.nunits = s.nunits;
             U.tail_first = s.t0 - res->begin; U.tail_n = s.tail_n;

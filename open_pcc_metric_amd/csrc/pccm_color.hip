@@ -104,12 +104,15 @@ __global__ __launch_bounds__(256) void k_color_rows(const double *__restrict__ o
 //   k_colsum_approx  plain sum of every 8192-element chunk (any order: a guess needs no more),
 //   k_colsum_units   one workgroup per chunk: wave w owns the 512 consecutive elements of sub-chunk w; the binade guess
 //                    of a sub-chunk = ilogb(approximate sum of everything in front of it); its total in units of that
-//                    binade, and whether every element rounded without a tie and below 2^53 units,
+//                    binade, and whether every element rounded without a tie and below 2^53 units.  A sub-chunk the walk
+//                    will probably reject (no guess, a tie, a crossing by the approximate sums) is listed, and gets the same
+//                    record once more for each of its eight groups of 64 elements, every group with a guess of its own,
 //   k_colsum_chain   one wave per column walks the chunks with the TRUE running sum t: a chunk (or, inside a chunk
-//                    that is not accepted whole, a sub-chunk) is accepted iff its guess equals ilogb(t), nothing tied
-//                    and t + total stays within the binade; a rejected sub-chunk (the ~log2(N) binade crossings, the
-//                    start at t = 0, ties, non-finite values) is redone from memory in groups of 64 elements with
-//                    the same test, and a rejected group is summed the plain way, one add after the other.
+//                    that is not accepted whole, a sub-chunk; inside a rejected sub-chunk, a group) is accepted iff its
+//                    guess equals ilogb(t), nothing tied and t + total stays within the binade; a rejected group (the
+//                    ~log2(N) binade crossings, the start at t = 0, ties, non-finite values) is summed the plain way, one
+//                    add after the other.  Everything the walk touches has been staged in LDS by the other fifteen waves.
+// Both directions of a pair go through the same three launches (ColsumJobs): the walk is one wave's latency, whatever runs beside it.
 // The result is the chain's result bit for bit whatever the guesses were (tests: tests/test_gpu_color.py against
 // np.add.reduce(axis=0) on random, tie-laden, wide-range and non-finite columns).
 constexpr int kSumThreads = 1024, kSumPer = 8, kSumChunk = kSumThreads * kSumPer, kSumWaves = kSumThreads / 64, kSumSub = kSumChunk / kSumWaves;
@@ -153,12 +156,13 @@ __device__ __forceinline__ double lane_value(double x, int l)
 struct SumSub {                // what k_colsum_units leaves per sub-chunk (512 elements)
     double total;              // SUM rint(x / u) in units of binade e
     int e;                     // the guessed binade (kNoGuess: none)
-    int ok;                    // every element rounded without a tie and below 2^53 units
+    int ok;                    // kRecOk: every element rounded without a tie and below 2^53 units; kRecZero: every element is +0
 };
+constexpr int kRecOk = 1, kRecZero = 2;    // (a run of zeros leaves ANY running sum as it is: acceptable whatever the binade)
 struct SumChunk {              // ... and per chunk (8192 elements)
     double total;              // of all sixteen sub-chunks, when they share one binade
     int e;                     // that binade
-    int whole;                 // the chunk may be accepted whole: one binade, no tie, no sub-chunk flagged
+    int whole;                 // kRecOk: the chunk may be accepted whole (one binade, no tie, no sub-chunk flagged); kRecZero: all zeros
 };
 constexpr int kNoGuess = -100000;
 // A sub-chunk is FLAGGED when the walk will probably have to redo it from its elements: no guess, a tie, or a binade crossing
@@ -168,14 +172,34 @@ constexpr int kStageSubs = 14;             // flagged sub-chunks staged per colu
 constexpr int kStageChunks = 14;           // ... and chunks whose sixteen records are staged
 constexpr int kSumMaxChunksLds = 1536;     // chunk records kept in LDS (12.6 M elements; beyond: read from memory as the walk goes)
 
-__global__ __launch_bounds__(kSumThreads) void k_colsum_approx(const double *__restrict__ cols, int64_t n, int64_t nchunks,
-                                                               double *__restrict__ approx, uint32_t *__restrict__ nflagged)
+// Up to two column triples per launch (the two directions of a pair: different lengths, the same three kernels).
+struct ColsumJob {
+    const double *cols;        // [3][n]
+    int64_t n, nchunks;
+    double *approx;            // [3][nchunks]
+    SumChunk *chunks;          // [3][nchunks]
+    SumSub *subs;              // [3][nchunks][16]
+    SumSub *groups;            // [3][flag_cap][8]: a flagged sub-chunk's groups of 64 elements, each with a guess of its own
+    uint32_t *nflag, *list;    // [3], [3][flag_cap]
+    double *out;               // [3]
+    unsigned long long *dbg;   // DIAG builds: [3][16] stamps and counts of the walk
+};
+struct ColsumJobs {
+    ColsumJob j[2];
+    int njobs, flag_cap;
+};
+
+__global__ __launch_bounds__(kSumThreads) void k_colsum_approx(ColsumJobs jobs)
 {
     __shared__ double s_p[kSumWaves];
-    const double *__restrict__ col = cols + (int64_t)blockIdx.y * n;
+    const ColsumJob &J = jobs.j[blockIdx.y / 3];
+    const int column = blockIdx.y % 3;
+    if ((int64_t)blockIdx.x >= J.nchunks) return;
+    const int64_t n = J.n;
+    const double *__restrict__ col = J.cols + (int64_t)column * n;
     const int64_t base = (int64_t)blockIdx.x * kSumChunk;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0) nflagged[blockIdx.y] = 0u;      // (the next kernel appends to the column's list)
+    if (blockIdx.x == 0 && tid == 0) J.nflag[column] = 0u;      // (the next kernel appends to the column's list)
     double p = 0.0;
 #pragma unroll
     for (int j = 0; j < kSumPer; ++j) {
@@ -189,19 +213,20 @@ __global__ __launch_bounds__(kSumThreads) void k_colsum_approx(const double *__r
     if (tid == 0) {
         double t = 0.0;
         for (int k = 0; k < kSumWaves; ++k) t += s_p[k];
-        approx[(int64_t)blockIdx.y * nchunks + blockIdx.x] = t;
+        J.approx[(int64_t)column * J.nchunks + blockIdx.x] = t;
     }
 }
 
-__global__ __launch_bounds__(kSumThreads) void k_colsum_units(const double *__restrict__ cols, int64_t n, int64_t nchunks,
-                                                              const double *__restrict__ approx, SumSub *__restrict__ subs,
-                                                              SumChunk *__restrict__ chunks, uint32_t *__restrict__ nflagged,
-                                                              uint32_t *__restrict__ flagged, int flag_cap)
+__global__ __launch_bounds__(kSumThreads) void k_colsum_units(ColsumJobs jobs)
 {
     __shared__ double s_red[kSumWaves], s_pre[kSumWaves + 1], s_tot[kSumWaves];
     __shared__ int s_e[kSumWaves], s_good[kSumWaves];
-    const double *__restrict__ col = cols + (int64_t)blockIdx.y * n;
-    const double *__restrict__ apx = approx + (int64_t)blockIdx.y * nchunks;
+    const ColsumJob &J = jobs.j[blockIdx.y / 3];
+    const int column = blockIdx.y % 3;
+    if ((int64_t)blockIdx.x >= J.nchunks) return;
+    const int64_t n = J.n, nchunks = J.nchunks;
+    const double *__restrict__ col = J.cols + (int64_t)column * n;
+    const double *__restrict__ apx = J.approx + (int64_t)column * nchunks;
     const int64_t base = (int64_t)blockIdx.x * kSumChunk;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // the sub-chunk's elements (consecutive: the walk's order is the index order), issued first
@@ -242,67 +267,168 @@ __global__ __launch_bounds__(kSumThreads) void k_colsum_units(const double *__re
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
     const int okw = __all(ok);
+    bool z = true;
+#pragma unroll
+    for (int j = 0; j < kSumPer; ++j) z = z && __double_as_longlong(x[j]) == 0ll;
+    const int zero = __all(z);
+    // flagged: the walk will probably want this sub-chunk's elements (no guess, a tie, or -- by the approximate sums -- the
+    // running sum leaves the binade inside it); only sub-chunks that hold elements.  (wave-uniform: every lane holds the sums)
+    const double end = start + mine;
+    const bool crossing = !(end < INFINITY) || !q.usable || ilogb(end) != q.e || part > q.room;
+    const bool sus = (base + (int64_t)w * kSumSub < n) && (!okw || crossing) && !zero;
+    uint32_t pos = 0xffffffffu;
+    if (sus) {
+        if (lane == 0) pos = atomicAdd(&J.nflag[column], 1u);
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+        if (pos < (uint32_t)jobs.flag_cap) {
+            // the same once more for each of its eight groups of 64 consecutive elements, every group with the binade the
+            // approximate sum in front of IT suggests: the walk then redoes a rejected sub-chunk from eight ready-made totals
+            // (and sums only the group a crossing falls into element by element)
+            double front = start;
+#pragma unroll
+            for (int j = 0; j < kSumPer; ++j) {
+                const Units qg = units_of(front);
+                double k;
+                const bool okg = unit_round(x[j], qg.inv_u, k) && qg.usable;
+                double tg = k, sg = x[j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    tg += __shfl_xor(tg, off);
+                    sg += __shfl_xor(sg, off);
+                }
+                const int okall = __all(okg), zall = __all(__double_as_longlong(x[j]) == 0ll);
+                if (lane == 0) {
+                    SumSub r;
+                    r.total = zall ? 0.0 : tg;
+                    r.e = qg.usable ? qg.e : kNoGuess;
+                    r.ok = (okall ? kRecOk : 0) | (zall ? kRecZero : 0);
+                    J.groups[((int64_t)column * jobs.flag_cap + pos) * kSumPer + j] = r;
+                }
+                front += sg;
+            }
+        }
+    }
     if (lane == 0) {
         SumSub r;
-        r.total = part;
+        r.total = zero ? 0.0 : part;
         r.e = q.usable ? q.e : kNoGuess;
-        r.ok = okw;
-        subs[((int64_t)blockIdx.y * nchunks + blockIdx.x) * kSumWaves + w] = r;
-        // flagged: the walk will probably want this sub-chunk's elements (no guess, a tie, or -- by the approximate sums -- the
-        // running sum leaves the binade inside it); only sub-chunks that hold elements
-        const double end = start + mine;
-        const bool crossing = !(end < INFINITY) || !q.usable || ilogb(end) != q.e || part > q.room;
-        const bool sus = (base + (int64_t)w * kSumSub < n) && (!okw || crossing);
-        if (sus) {
-            const uint32_t pos = atomicAdd(&nflagged[blockIdx.y], 1u);
-            if (pos < (uint32_t)flag_cap) flagged[(int64_t)blockIdx.y * flag_cap + pos] = (uint32_t)(blockIdx.x * kSumWaves + w);
-        }
-        s_tot[w] = part;
+        r.ok = (okw ? kRecOk : 0) | (zero ? kRecZero : 0);
+        J.subs[((int64_t)column * nchunks + blockIdx.x) * kSumWaves + w] = r;
+        if (pos < (uint32_t)jobs.flag_cap) J.list[(int64_t)column * jobs.flag_cap + pos] = (uint32_t)(blockIdx.x * kSumWaves + w);
+        s_tot[w] = r.total;
         s_e[w] = r.e;
-        s_good[w] = okw && !sus;
+        s_good[w] = zero ? 2 : (okw && !sus);         // (2: a sub-chunk of zeros fits every binade)
     }
     __syncthreads();
     if (tid == 0) {
         SumChunk c;
         c.total = 0.0;
-        c.e = s_e[0];
-        c.whole = 1;
+        c.e = kNoGuess;
+        bool whole = true, zeros = true;
         for (int k = 0; k < kSumWaves; ++k) {
             c.total += s_tot[k];                      // (integers: exact below 2^53; beyond, the walk's room test fails anyway)
-            c.whole = c.whole && s_good[k] && s_e[k] == c.e && c.e != kNoGuess;
+            if (s_good[k] == 2) continue;             // zeros: any binade
+            if (zeros) c.e = s_e[k];                  // the first sub-chunk that holds something decides the chunk's binade
+            zeros = false;
+            whole = whole && s_good[k] && s_e[k] == c.e && c.e != kNoGuess;
         }
-        chunks[(int64_t)blockIdx.y * nchunks + blockIdx.x] = c;
+        c.whole = zeros ? (kRecOk | kRecZero) : (whole ? kRecOk : 0);
+        J.chunks[(int64_t)column * nchunks + blockIdx.x] = c;
     }
 }
 
-__global__ __launch_bounds__(kSumThreads) void k_colsum_chain(const double *__restrict__ cols, int64_t n, int64_t nchunks,
-                                                              const SumSub *__restrict__ subs, const SumChunk *__restrict__ chunks,
-                                                              const uint32_t *__restrict__ nflagged, const uint32_t *__restrict__ flagged,
-                                                              int flag_cap, double *__restrict__ out)
+// inclusive prefix sums over the wave's 64 lanes: four DPP row shifts inside the rows of sixteen (a lane whose source lies outside
+// its row keeps the 0 it was given), the three row totals through v_readlane.  (Non-negative integer-valued doubles here: exact
+// below 2^53, monotone beyond.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(uint32_t)lo);
+}
+
+__device__ __forceinline__ double wave_prefix(double v, int lane)
+{
+    v += dpp_row<0x111>(v);        // row_shr:1
+    v += dpp_row<0x112>(v);        // row_shr:2
+    v += dpp_row<0x114>(v);        // row_shr:4
+    v += dpp_row<0x118>(v);        // row_shr:8
+    const double r0 = lane_value(v, 15), r1 = lane_value(v, 31), r2 = lane_value(v, 47);
+    const int row = lane >> 4;
+    const double front = row == 0 ? 0.0 : row == 1 ? r0 : row == 2 ? r0 + r1 : (r0 + r1) + r2;
+    return v + front;
+}
+
+// The walk's one step, at every level (chunks, sub-chunks, groups, elements): lanes [lo, hi) hold consecutive records -- `tot`
+// the record's total in units of the running sum's binade, `good` that it may be taken so (guess = the sum's binade, nothing
+// tied; or all zeros).  Takes the longest prefix of good records whose totals fit below the binade's end -- t + u * (sum of the
+// totals) is then what adding them one after the other gives, exactly -- and returns the first lane it did not take (hi: all).
+// `again`: the sum landed exactly on the binade's end, so the record that did not fit deserves a second look at this level.
+__device__ __forceinline__ int accept_run(double tot, bool good, int lo, int hi, int lane, double &t, Units &q, bool &again)
+{
+    again = false;
+    const bool in = lane >= lo && lane < hi;
+    const double p = wave_prefix(in && good ? tot : 0.0, lane);
+    const unsigned long long bad = __ballot(in && (!good || !(p <= q.room)));
+    const int f = bad ? __ffsll((long long)bad) - 1 : hi;
+    if (f > lo) {
+        const double s = lane_value(p, f - 1);
+        if (s > 0.0) {                                // (zeros only: nothing to add, and q may be unusable)
+            t = t + s * q.u;                          // exact: (t / u + s) * u with t / u + s <= 2^53
+            q.room -= s;
+            if (q.room == 0.0) {                      // (the sum landed on 2^(e+1) exactly: the next binade begins here)
+                q = units_of(t);
+                again = true;
+            }
+        }
+    }
+    return f;
+}
+
+__device__ __forceinline__ bool record_good(int flags, int e, const Units &q)
+{
+    return (flags & kRecZero) || ((flags & kRecOk) && q.usable && e == q.e);
+}
+
+__global__ __launch_bounds__(kSumThreads) void k_colsum_chain(ColsumJobs jobs)
 {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];           // (kStageSubs + 1) x 512 staged elements | kSumMaxChunksLds chunk records
     SumChunk *const s_chunk = reinterpret_cast<SumChunk *>(s_dyn + (kStageSubs + 1) * kSumSub);
-    __shared__ SumSub s_sub[kStageChunks][kSumWaves];
+    __shared__ SumSub s_sub[kStageChunks][kSumWaves], s_grp[kStageSubs][kSumPer];
     __shared__ uint32_t s_sid[kStageSubs], s_cid[kStageChunks];
     __shared__ int s_nsub, s_nchunk;
-    const double *__restrict__ col = cols + (int64_t)blockIdx.x * n;
-    const SumSub *__restrict__ sub = subs + (int64_t)blockIdx.x * nchunks * kSumWaves;
-    const SumChunk *__restrict__ chk = chunks + (int64_t)blockIdx.x * nchunks;
+    const ColsumJob &J = jobs.j[blockIdx.x / 3];
+    const int column = blockIdx.x % 3, flag_cap = jobs.flag_cap;
+    const int64_t n = J.n, nchunks = J.nchunks;
+    const double *__restrict__ col = J.cols + (int64_t)column * n;
+    const SumSub *__restrict__ sub = J.subs + (int64_t)column * nchunks * kSumWaves;
+    const SumChunk *__restrict__ chk = J.chunks + (int64_t)column * nchunks;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // ---- everything the walk is likely to need, into LDS: all chunk records, the flagged sub-chunks' elements and their
-    //      chunks' sub-chunk records (first come first served: the list is in no particular order)
+#ifdef PCCM_DIAG
+    unsigned long long dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    dg[0] = __builtin_readcyclecounter();
+#define DG(i, v) dg[i] += (v)
+#define DGT() __builtin_readcyclecounter()
+#else
+#define DG(i, v)
+#define DGT() 0ull
+#endif
+    // ---- everything the walk is likely to need, into LDS: all chunk records, the flagged sub-chunks' elements, their groups'
+    //      records and their chunks' sub-chunk records (first come first served: the list is in no particular order)
     const int64_t nlds = nchunks < kSumMaxChunksLds ? nchunks : kSumMaxChunksLds;
     for (int64_t k = tid; k < nlds; k += kSumThreads) s_chunk[k] = chk[k];
     __shared__ uint32_t s_flag[64];
-    const uint32_t have = nflagged[blockIdx.x];
-    const int cnt = (int)(have < (uint32_t)flag_cap ? have : (uint32_t)flag_cap) < 64 ? (int)(have < (uint32_t)flag_cap ? have : (uint32_t)flag_cap) : 64;
-    if (tid < cnt) s_flag[tid] = flagged[(int64_t)blockIdx.x * flag_cap + tid];      // (one coalesced load: a lane walking the list alone
-    __syncthreads();                                                                   //  pays a memory round trip per entry)
+    const uint32_t have = J.nflag[column];
+    const int capped = (int)(have < (uint32_t)flag_cap ? have : (uint32_t)flag_cap), cnt = capped < 64 ? capped : 64;
+    if (tid < cnt) s_flag[tid] = J.list[(int64_t)column * flag_cap + tid];    // (one coalesced load: a lane walking the list alone
+    __syncthreads();                                                           //  pays a memory round trip per entry)
     if (tid == 0) {
         int ns = 0, nc = 0;
         for (int k = 0; k < cnt; ++k) {
             const uint32_t id = s_flag[k];
-            if (ns < kStageSubs) s_sid[ns++] = id;
+            if (ns < kStageSubs) s_sid[ns++] = id;                            // (staged slot k = list position k)
             const uint32_t c = id / (uint32_t)kSumWaves;
             bool seen = false;
             for (int j = 0; j < nc; ++j) seen = seen || s_cid[j] == c;
@@ -320,40 +446,59 @@ __global__ __launch_bounds__(kSumThreads) void k_colsum_chain(const double *__re
             s_dyn[k * kSumSub + g * 64 + lane] = i < n ? col[i] : 0.0;
         }
     }
+    for (int k = tid; k < s_nsub * kSumPer; k += kSumThreads) s_grp[k / kSumPer][k % kSumPer] = J.groups[((int64_t)column * flag_cap + k / kSumPer) * kSumPer + (k % kSumPer)];
     for (int k = tid; k < s_nchunk * kSumWaves; k += kSumThreads) s_sub[k / kSumWaves][k % kSumWaves] = sub[(int64_t)s_cid[k / kSumWaves] * kSumWaves + (k % kSumWaves)];
     __syncthreads();
     if (w != 0) return;
-    // ---- the walk (one wave) ---------------------------------------------------------------------------------------------
+    DG(1, DGT());
+    // ---- the walk (one wave).  Every step takes a RUN of records at once (accept_run): as many chunks as fit below the end of
+    //      the binade, then -- inside the chunk that did not fit -- sub-chunks, groups, elements; the element the running sum crosses
+    //      into the next binade with is added the plain way, and the walk goes on one level up as soon as a run has been taken.
     double t = 0.0;
-    Units q = units_of(t);                            // (ilogb / ldexp are costly: only redone after a plain-sum group)
+    Units q = units_of(t);
     const int nsub = s_nsub, nchk = s_nchunk;
-    for (int64_t c = 0; c < nchunks; ++c) {
-        const SumChunk cc = c < nlds ? s_chunk[c] : chk[c];
-        if (q.usable && cc.whole && cc.e == q.e && cc.total <= q.room) {
-            t = t + cc.total * q.u;                   // exact: (t / u + total) * u with t / u + total <= 2^53
-            q.room -= cc.total;
-            if (q.room == 0.0) q = units_of(t);       // (the sum landed on 2^(e+1) exactly: the next binade begins here)
-            continue;
+    int64_t c = 0;
+    while (c < nchunks) {
+        {
+            const int64_t ci = c + lane;
+            SumChunk cc;
+            cc.total = 0.0;
+            cc.e = kNoGuess;
+            cc.whole = 0;
+            if (ci < nchunks) cc = ci < nlds ? s_chunk[ci] : chk[ci];
+            const int hi = nchunks - c < 64 ? (int)(nchunks - c) : 64;
+            bool again;
+            const int f = accept_run(cc.total, record_good(cc.whole, cc.e, q), 0, hi, lane, t, q, again);
+            DG(3, f);
+            c += f;
+            if (f == hi || again) continue;           // (all of them, or the sum is in another binade now: look again)
         }
-        // sub-chunk by sub-chunk: the chunk's sixteen records (lanes 0 .. 15), staged or fetched
+        [[maybe_unused]] const unsigned long long tc0 = DGT();
+        // chunk c sub-chunk by sub-chunk: its sixteen records (lanes 0 .. 15), staged or fetched
         const unsigned long long hitc = __ballot(lane < nchk && s_cid[lane < kStageChunks ? lane : 0] == (uint32_t)c);   // (every lane looks at one entry)
         const int slot = hitc ? __ffsll((long long)hitc) - 1 : -1;
         const int l16 = lane < kSumWaves ? lane : 0;
         const SumSub cur = slot >= 0 ? s_sub[slot][l16] : sub[c * kSumWaves + l16];
-        for (int ww = 0; ww < kSumWaves; ++ww) {
-            const double tw = __shfl(cur.total, ww);
-            const int ew = __shfl(cur.e, ww), okw = __shfl(cur.ok, ww);
-            if (q.usable && okw && ew == q.e && tw <= q.room) {
-                t = t + tw * q.u;
-                q.room -= tw;
-                if (q.room == 0.0) q = units_of(t);
-                continue;
+        int w0 = 0;
+        while (w0 < kSumWaves) {
+            if (c * kSumChunk + (int64_t)w0 * kSumSub >= n) break;
+            {
+                bool again;
+                const int f = accept_run(cur.total, record_good(cur.ok, cur.e, q), w0, kSumWaves, lane, t, q, again);
+                DG(4, f - w0);
+                w0 = f;
+                if (f == kSumWaves || again) continue;
+                if (c * kSumChunk + (int64_t)w0 * kSumSub >= n) break;
             }
-            // a rejected sub-chunk in groups of 64 elements: from the staged copy, or from memory (all of it in flight at once)
-            const int64_t base = c * kSumChunk + (int64_t)ww * kSumSub;
-            if (base >= n) break;
-            const unsigned long long hits = __ballot(lane < nsub && s_sid[lane < kStageSubs ? lane : 0] == (uint32_t)(c * kSumWaves + ww));
+            [[maybe_unused]] const unsigned long long ts0 = DGT();
+            // sub-chunk w0 in groups of 64 elements: from the staged copy, or from memory (all of it in flight at once)
+            const int64_t base = c * kSumChunk + (int64_t)w0 * kSumSub;
+            const unsigned long long hits = __ballot(lane < nsub && s_sid[lane < kStageSubs ? lane : 0] == (uint32_t)(c * kSumWaves + w0));
             int st = hits ? __ffsll((long long)hits) - 1 : -1;
+            SumSub mine;                              // lanes 0 .. 7: the groups' ready-made records (none for a sub-chunk fetched now)
+            mine.total = 0.0;
+            mine.e = kNoGuess;
+            mine.ok = 0;
             if (st < 0) {                             // not flagged (a guess just beside a binade border): fetched now, into the spare slot
                 st = kStageSubs;
 #pragma unroll
@@ -361,29 +506,58 @@ __global__ __launch_bounds__(kSumThreads) void k_colsum_chain(const double *__re
                     const int64_t i = base + g * 64 + lane;
                     s_dyn[st * kSumSub + g * 64 + lane] = i < n ? col[i] : 0.0;
                 }
+            } else {
+                mine = s_grp[st][lane & (kSumPer - 1)];
             }
             const double *xp = s_dyn + st * kSumSub;
-#pragma unroll 1
-            for (int g = 0; g < kSumSub / 64; ++g) {  // (rolled loops: this is cold code, and one wave pays every instruction-cache miss alone)
-                const double xv = xp[g * 64 + lane];
-                double k;
-                const bool okg = unit_round(xv, q.inv_u, k) && q.usable;
-                double tg = k;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) tg += __shfl_xor(tg, off);
-                if (__all(okg) && tg <= q.room) {
-                    t = t + tg * q.u;
-                    q.room -= tg;                     // exact (integers below 2^53): still t's distance to 2^(e+1) in units
-                    if (q.room == 0.0) q = units_of(t);
-                } else {
-#pragma unroll 1
-                    for (int e = 0; e < 64; ++e) t = t + lane_value(xv, e);   // the reference's own order (+ 0.0 beyond the column's end)
-                    q = units_of(t);
+            int g0 = 0;
+            while (g0 < kSumPer) {
+                {
+                    bool again;
+                    const int f = accept_run(mine.total, record_good(mine.ok, mine.e, q), g0, kSumPer, lane, t, q, again);
+                    DG(5, f - g0);
+                    g0 = f;
+                    if (f == kSumPer || again) continue;
                 }
+                // group g0 element by element: runs again, broken by the elements that tie or carry the sum into the next binade
+                [[maybe_unused]] const unsigned long long tp0 = DGT();
+                const double xv = xp[g0 * 64 + lane];
+                int lo = 0, dry = 0;
+                while (lo < 64) {
+                    if (dry >= 2) {                   // nothing fits (non-finite values, ties in a row): the reference's own order
+#pragma unroll 1
+                        for (int e = lo; e < 64; ++e) t = t + lane_value(xv, e);
+                        q = units_of(t);
+                        break;
+                    }
+                    double k;
+                    const bool rounds = unit_round(xv, q.inv_u, k) && q.usable, zero = __double_as_longlong(xv) == 0ll;
+                    bool again;
+                    const int f = accept_run(zero ? 0.0 : k, zero || rounds, lo, 64, lane, t, q, again);
+                    dry = f > lo ? 0 : dry + 1;
+                    if (f < 64) {
+                        t = t + lane_value(xv, f);
+                        q = units_of(t);
+                        DG(7, 1);
+                    }
+                    lo = f + 1;
+                }
+                DG(6, 1);
+                DG(8, DGT() - tp0);
+                ++g0;
             }
+            DG(9, DGT() - ts0);
+            ++w0;
         }
+        DG(10, DGT() - tc0);
+        ++c;
     }
-    if (lane == 0) out[blockIdx.x] = t;
+    if (lane == 0) J.out[column] = t;
+#ifdef PCCM_DIAG
+    dg[2] = __builtin_readcyclecounter();
+    if (lane == 0 && J.dbg)
+        for (int k = 0; k < 12; ++k) J.dbg[column * 16 + k] = dg[k];
+#endif
 }
 
 // uchar colours (what PLY / PCD / PTS files hold) widened on the device: k / 255.0, the very division the host readers
@@ -413,24 +587,52 @@ int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, con
     return PCCM_OK;
 }
 
-int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *out3)
+int launch_color_colsums(pccm_ctx *ctx, int njobs, const double *const cols[2], const int64_t n[2], double *const out3[2])
 {
     ProfScope ps(ctx, PCCM_K_REDUCE);
-    const int64_t nchunks = (n + kSumChunk - 1) / kSumChunk;
     constexpr int kFlagCap = 64;          // flagged sub-chunks listed per column (the chain stages the first kStageSubs of them)
-    // scratch: [3][nchunks] approximate chunk sums | [3][nchunks] chunk records | [3][nchunks][16] sub-chunk records | counts + lists
+    // scratch per job: [3][nchunks] approximate chunk sums | [3][nchunks] chunk records | [3][nchunks][16] sub-chunk records |
+    //                  [3][kFlagCap][8] group records | counts | lists
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t o_chunk = up((size_t)3 * nchunks * sizeof(double)), o_sub = o_chunk + up((size_t)3 * nchunks * sizeof(SumChunk)),
-                 o_cnt = o_sub + up((size_t)3 * nchunks * kSumWaves * sizeof(SumSub)), o_list = o_cnt + 256, total = o_list + up((size_t)3 * kFlagCap * 4);
+    size_t off[2][6], total = 0;
+    int64_t nchunks[2] = {0, 0}, most = 0;
+    for (int k = 0; k < njobs; ++k) {
+        nchunks[k] = (n[k] + kSumChunk - 1) / kSumChunk;
+        most = nchunks[k] > most ? nchunks[k] : most;
+        off[k][0] = total;
+        off[k][1] = off[k][0] + up((size_t)3 * nchunks[k] * sizeof(double));
+        off[k][2] = off[k][1] + up((size_t)3 * nchunks[k] * sizeof(SumChunk));
+        off[k][3] = off[k][2] + up((size_t)3 * nchunks[k] * kSumWaves * sizeof(SumSub));
+        off[k][4] = off[k][3] + up((size_t)3 * kFlagCap * kSumPer * sizeof(SumSub));
+        off[k][5] = off[k][4] + 256;
+        total = off[k][5] + up((size_t)3 * kFlagCap * 4);
+    }
+    const size_t o_dbg = total;
+    total += 2 * 3 * 16 * sizeof(unsigned long long);
     int rc = ensure(ctx, ctx->colsum_scratch, total);
     if (rc) return rc;
     char *base = (char *)ctx->colsum_scratch.p;
-    double *approx = (double *)base;
-    SumChunk *chunks = (SumChunk *)(base + o_chunk);
-    SumSub *subs = (SumSub *)(base + o_sub);
-    uint32_t *nflag = (uint32_t *)(base + o_cnt), *list = (uint32_t *)(base + o_list);
+    ColsumJobs jobs;
+    jobs.njobs = njobs;
+    jobs.flag_cap = kFlagCap;
+    for (int k = 0; k < 2; ++k) {
+        ColsumJob &J = jobs.j[k];
+        const int s = k < njobs ? k : 0;
+        J.cols = cols[s];
+        J.n = n[s];
+        J.nchunks = nchunks[s];
+        J.approx = (double *)(base + off[s][0]);
+        J.chunks = (SumChunk *)(base + off[s][1]);
+        J.subs = (SumSub *)(base + off[s][2]);
+        J.groups = (SumSub *)(base + off[s][3]);
+        J.nflag = (uint32_t *)(base + off[s][4]);
+        J.list = (uint32_t *)(base + off[s][5]);
+        J.out = out3[s];
+        J.dbg = (unsigned long long *)(base + o_dbg) + s * 48;
+    }
     const size_t dyn = (size_t)(kStageSubs + 1) * kSumSub * sizeof(double) + (size_t)kSumMaxChunksLds * sizeof(SumChunk);
-    static_assert((size_t)(kStageSubs + 1) * kSumSub * sizeof(double) + kSumMaxChunksLds * sizeof(SumChunk) + kStageChunks * kSumWaves * sizeof(SumSub) + 256 <= 96 * 1024,
+    static_assert((size_t)(kStageSubs + 1) * kSumSub * sizeof(double) + kSumMaxChunksLds * sizeof(SumChunk) + kStageChunks * kSumWaves * sizeof(SumSub) +
+                          kStageSubs * kSumPer * sizeof(SumSub) + 512 <= 96 * 1024,
                   "the chain kernel's LDS stays below 96 KB");
     if (!ctx->colsum_configured) {
         // more than 64 KB of LDS per workgroup needs the opt-in -- a per-DEVICE attribute: kept with the context (which is bound to
@@ -438,13 +640,32 @@ int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *ou
         PCCM_HIP(hipFuncSetAttribute((const void *)k_colsum_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         ctx->colsum_configured = true;
     }
-    dim3 grid((unsigned)nchunks, 3);
-    hipLaunchKernelGGL(k_colsum_approx, grid, dim3(kSumThreads), 0, ctx->stream, cols, n, nchunks, approx, nflag);
-    hipLaunchKernelGGL(k_colsum_units, grid, dim3(kSumThreads), 0, ctx->stream, cols, n, nchunks, (const double *)approx, subs, chunks, nflag, list, kFlagCap);
-    hipLaunchKernelGGL(k_colsum_chain, dim3(3), dim3(kSumThreads), dyn, ctx->stream, cols, n, nchunks, (const SumSub *)subs, (const SumChunk *)chunks,
-                       (const uint32_t *)nflag, (const uint32_t *)list, kFlagCap, out3);
+    dim3 grid((unsigned)most, 3 * njobs);
+    hipLaunchKernelGGL(k_colsum_approx, grid, dim3(kSumThreads), 0, ctx->stream, jobs);
+    hipLaunchKernelGGL(k_colsum_units, grid, dim3(kSumThreads), 0, ctx->stream, jobs);
+    hipLaunchKernelGGL(k_colsum_chain, dim3(3 * njobs), dim3(kSumThreads), dyn, ctx->stream, jobs);
     PCCM_HIP(hipGetLastError());
+#ifdef PCCM_DIAG
+    if (getenv("PCCM_COLSUM_STAMP")) {
+        unsigned long long h[96];
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+        PCCM_HIP(hipMemcpy(h, base + o_dbg, sizeof(h), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3 * njobs; ++k) {
+            const unsigned long long *d = h + (k / 3) * 48 + (k % 3) * 16;
+            fprintf(stderr, "colsum job %d col %d: stage %llu walk %llu clocks | chunks taken %llu subs %llu groups %llu | groups by element %llu plain adds %llu | element clk %llu sub-loop clk %llu chunk-loop clk %llu\n",
+                    k / 3, k % 3, d[1] - d[0], d[2] - d[1], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]);
+        }
+    }
+#endif
     return PCCM_OK;
+}
+
+int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *out3)
+{
+    const double *c[2] = {cols, cols};
+    const int64_t nn[2] = {n, n};
+    double *o[2] = {out3, out3};
+    return launch_color_colsums(ctx, 1, c, nn, o);
 }
 
 }  // namespace pccm

@@ -521,9 +521,9 @@ __global__ __launch_bounds__(256) void k_grid_tail(QueryJobs jobs, GridGeom g, R
     if (threadIdx.x == 0) {
         // this job's tail list is complete (the ring-1 kernel of the previous launch wrote it): wait until all of it is retired
         const uint32_t want = __hip_atomic_load(&jobs.j[jb].counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t ok = 0u;
-        for (uint32_t k = 0; k < ts.delay; ++k) __builtin_amdgcn_s_sleep(127);
-        for (uint32_t spin = 0; spin < (1u << 21); ++spin) {
+        uint32_t ok = want == 0u ? 1u : 0u;          // (an empty tail list -- the rule on voxelised content -- has nothing to wait for)
+        for (uint32_t k = 0; k < ts.delay && !ok; ++k) __builtin_amdgcn_s_sleep(127);
+        for (uint32_t spin = 0; spin < (1u << 21) && !ok; ++spin) {
             uint32_t got = 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k)

@@ -220,6 +220,16 @@ struct pccm_ctx {
     pccm::DevBuf color_cols, color_idx;   // colour pass: squares as three columns / caller-supplied neighbour rows
     pccm::DevBuf colsum_scratch;          // ... the column sums' chunk guesses and sub-chunk totals (pccm_color.hip)
     bool colsum_configured = false;       // k_colsum_chain's LDS opt-in was set on this context's device
+    // pccm_color_reduce works on BOTH directions when it can (the same launches serve two column triples; the walk behind
+    // NumPy's summation order is one wave's latency however many run side by side) and keeps the other direction's answer
+    // here until that direction is asked for -- or a search, new colours or another scheme make it stale
+    struct ColorMemo {
+        bool valid = false, range_bad = false;
+        int dir = 0, scheme = 0;
+        double scale = 0.0, sum[3] = {0, 0, 0}, max[3] = {0, 0, 0};
+        uint64_t gen = 0, rgb_gen = 0;
+    } color_memo;
+    uint64_t rgb_gen = 1;                 // bumped by every colour upload
     pccm::Grid grid;
     pccm::DevBuf g_cell_of, g_rank, g_hist, g_blocksum, g_qrecs;   // grid-engine scratch (g_qrecs: cell-sorted shard rows)
     pccm::DevBuf g_bins, g_tmp;            // grid build: per-tile bin histogram + scan state; bin-partitioned records
@@ -343,7 +353,9 @@ struct UnitJob {                // one per-point array to reduce (k_unit_jobs): 
     // records of layout 1 (the matched record {rx, ry, rz, row}, 16 bytes): field 0 = the squared distance to row row0 + i of the
     // iterating cloud (q32), field 1 = err . normal[row0 + i] (metric.py:146-153), both formed here -- the rows and the searched
     // cloud's row-indexed normals are read in row order, i.e. coalesced, where the search would have gathered the normal
-    int defer;                  // 0: no; 1: normals as 16-byte fp32-exact words (nrm32); 2: as fp64 rows (nrm64); 3: no normals (field 0 only)
+    int defer;                  // 0: no; 1: normals as 16-byte fp32-exact words (nrm32); 2: as fp64 rows (nrm64); 3: no normals (field 0 only);
+                                // 4 / 5: as 1 / 2 with the normal of the MATCHED row (the record's row: --normal-index neighbour)
+    int64_t nrm_rows;           // rows of the searched cloud's normals (bounds the gather of 4 / 5)
     const double *nrm64;
     const float4 *nrm32;
     const float4 *q32;          // iterating cloud, one fp32 word per row (Cloud::xyz32r)
@@ -384,6 +396,7 @@ int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, con
                       int64_t n_other, int scheme, double scale, int what, double *out,
                       unsigned long long *maxkeys, unsigned int *bad);
 int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *out3);
+int launch_color_colsums(pccm_ctx *ctx, int njobs, const double *const cols[2], const int64_t n[2], double *const out3[2]);
 int launch_colors_from_u8(pccm_ctx *ctx, const unsigned char *src, int64_t n3, double *out);
 
 }  // namespace pccm

@@ -244,6 +244,7 @@ struct UnitView {               // the fields of a job the inner loop needs, in 
     const double *val;
     int stride, off0, off1, sq0, sq1;
     int defer;                  // UnitJob::defer
+    int64_t nrm_rows;           // UnitJob::nrm_rows
     const double *nrm64;
     const float4 *nrm32;
     const float4 *q32;
@@ -253,8 +254,11 @@ struct UnitView {               // the fields of a job the inner loop needs, in 
 // The two fields of a result record of layout 1 (the matched record {rx, ry, rz, row}, NNOut::layout) for row `row` of the
 // iterating cloud: squared distance -- nanoflann's accumulation order, as every search kernel evaluates it (gdist64, pccm_grid.h)
 // -- and err . normal[row] -- the FMA chain of emit_result / K3; bit for bit what the searches would have stored.
+// defer 4 / 5: the normal of the MATCHED row (--normal-index neighbour; the record carries the row), a gather where 1 / 2 stream;
+// nrm_rows bounds it (a row outside the searched cloud cannot be in a record the searches wrote: clamped all the same).
 __device__ __forceinline__ void matched_fields(const float4 rec, const float4 *__restrict__ q32, int defer, const double *__restrict__ nrm64,
-                                               const float4 *__restrict__ nrm32, int64_t row, bool want_proj, double &d2, double &proj)
+                                               const float4 *__restrict__ nrm32, int64_t row, bool want_proj, double &d2, double &proj,
+                                               int64_t nrm_rows = 0)
 {
     const float4 q = q32[row];
     const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
@@ -263,11 +267,16 @@ __device__ __forceinline__ void matched_fields(const float4 rec, const float4 *_
     proj = 0.0;
     if (want_proj && defer != 3) {
         double n0, n1, n2;
-        if (defer == 1) {
-            const float4 t = nrm32[row];
+        int64_t nr = row;
+        if (defer >= 4) {
+            nr = (int64_t)__float_as_int(rec.w);
+            nr = nr < 0 ? 0 : (nr >= nrm_rows ? nrm_rows - 1 : nr);
+        }
+        if (defer == 1 || defer == 4) {
+            const float4 t = nrm32[nr];
             n0 = (double)t.x; n1 = (double)t.y; n2 = (double)t.z;
         } else {
-            n0 = nrm64[3 * row]; n1 = nrm64[3 * row + 1]; n2 = nrm64[3 * row + 2];
+            n0 = nrm64[3 * nr]; n1 = nrm64[3 * nr + 1]; n2 = nrm64[3 * nr + 2];
         }
         proj = __dmul_rn(ex, n0);
         proj = __fma_rn(ey, n1, proj);
@@ -282,14 +291,14 @@ __device__ __forceinline__ UnitView unit_view(const UnitJob &J)
     w.stride = J.stride;
     w.off0 = J.c[0].off; w.off1 = J.c[1].off;
     w.sq0 = J.c[0].square; w.sq1 = J.c[1].square;
-    w.defer = J.defer; w.nrm64 = J.nrm64; w.nrm32 = J.nrm32; w.q32 = J.q32; w.row0 = J.row0;
+    w.defer = J.defer; w.nrm64 = J.nrm64; w.nrm32 = J.nrm32; w.q32 = J.q32; w.row0 = J.row0; w.nrm_rows = J.nrm_rows;
     return w;
 }
 
 __device__ __forceinline__ void unit_load(const UnitView &J, int64_t i, double v[2])      // the load alone (callers batch them)
 {
     if (J.stride >= 2 && J.defer) {
-        matched_fields(reinterpret_cast<const float4 *>(J.val)[i], J.q32, J.defer, J.nrm64, J.nrm32, J.row0 + i, true, v[0], v[1]);
+        matched_fields(reinterpret_cast<const float4 *>(J.val)[i], J.q32, J.defer, J.nrm64, J.nrm32, J.row0 + i, true, v[0], v[1], J.nrm_rows);
     } else if (J.stride >= 2) {
         const double2 t = *reinterpret_cast<const double2 *>(&J.val[i * J.stride]);
         v[0] = t.x;
@@ -480,11 +489,11 @@ __global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
         const double *__restrict__ nrm64 = J.nrm64;
         const float4 *__restrict__ nrm32 = J.nrm32;
         const float4 *__restrict__ q32 = J.q32;
-        const int64_t row0 = J.row0;
+        const int64_t row0 = J.row0, nrm_rows = J.nrm_rows;
         auto cols = [&](const double *p, int64_t e, double out[NC]) {
             if (DEFER) {
                 double x, y;
-                matched_fields(*reinterpret_cast<const float4 *>(p), q32, DEFER, nrm64, nrm32, row0 + e, CFG != 1, x, y);
+                matched_fields(*reinterpret_cast<const float4 *>(p), q32, DEFER, nrm64, nrm32, row0 + e, CFG != 1, x, y, nrm_rows);
                 if (CFG == 0) { out[0] = x; out[1] = __dmul_rn(y, y); }
                 else if (CFG == 1) out[0] = x;
                 else if (CFG == 2) out[0] = __dmul_rn(y, y);
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(256) void k_unit_lean(UnitJobs jobs)
     double w[NC];
     if (DEFER) {
         double x, y;
-        matched_fields(*reinterpret_cast<const float4 *>(p), J.q32, DEFER, J.nrm64, J.nrm32, J.row0 + J.tail_first + e, CFG != 1, x, y);
+        matched_fields(*reinterpret_cast<const float4 *>(p), J.q32, DEFER, J.nrm64, J.nrm32, J.row0 + J.tail_first + e, CFG != 1, x, y, J.nrm_rows);
         if (CFG == 0) { w[0] = x; w[1] = __dmul_rn(y, y); }
         else if (CFG == 1) w[0] = x;
         else if (CFG == 2) w[0] = __dmul_rn(y, y);
@@ -646,6 +655,10 @@ int launch_unit_jobs(pccm_ctx *ctx, const UnitJobs &jobs)
     case 128 + 2 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<2, 1, 2>), grid, block, 0, ctx->stream, jobs); break;
     case 128 + 2 * 4 + 2: hipLaunchKernelGGL((k_unit_lean<2, 2, 2>), grid, block, 0, ctx->stream, jobs); break;
     case 192 + 2 * 4 + 1: hipLaunchKernelGGL((k_unit_lean<2, 1, 3>), grid, block, 0, ctx->stream, jobs); break;     // ... no normals: distances only
+    case 256 + 2 * 4 + 0: hipLaunchKernelGGL((k_unit_lean<2, 0, 4>), grid, block, 0, ctx->stream, jobs); break;     // ... the matched row's normal, fp32-exact
+    case 256 + 2 * 4 + 2: hipLaunchKernelGGL((k_unit_lean<2, 2, 4>), grid, block, 0, ctx->stream, jobs); break;
+    case 320 + 2 * 4 + 0: hipLaunchKernelGGL((k_unit_lean<2, 0, 5>), grid, block, 0, ctx->stream, jobs); break;     // ... fp64
+    case 320 + 2 * 4 + 2: hipLaunchKernelGGL((k_unit_lean<2, 2, 5>), grid, block, 0, ctx->stream, jobs); break;
     default: hipLaunchKernelGGL(k_unit_jobs, grid, block, 0, ctx->stream, jobs); break;      // mixed shapes; signed projections (min / max of -0.0 and 0.0: fmin / fmax there)
     }
     PCCM_HIP(hipGetLastError());

@@ -52,6 +52,24 @@ __constant__ __attribute__((aligned(16))) uint32_t c_vox_rows[kVoxRowsPadded] = 
     0xffff0808, 0xffff0808, 0xffff0808       // padding to whole quadruples: rows nobody can want (row (0, 0) again, at a distance beyond reach)
 };
 
+// Every voxel offset at EXACTLY distance^2 d2 from a query, for d2 <= kVoxNear, as dz + 8 | (dy + 8) << 5 | dx << 10 with dx >= 0 (the
+// walk looks at both x + dx and x - dx); c_vox_near_start[d2] .. [d2 + 1] is the list of d2.  The matched-row search of a query
+// whose nearest voxel is that close -- nearly all of them on decoded content -- looks at these <= 24 places instead of walking
+// every row within reach (section 5 of k_vox_query).
+constexpr int kVoxNear = 16, kVoxNearEntries = 153;
+__constant__ uint16_t c_vox_near[kVoxNearEntries] = {
+    0x108, 0x107, 0xe8, 0x508, 0x128, 0x109, 0xe7, 0x507, 0x127, 0x4e8, 0x528, 0xe9, 0x509, 0x129, 0x4e7, 0x527, 0x4e9, 0x529, 0x106,
+    0xc8, 0x908, 0x148, 0x10a, 0xe6, 0x506, 0x126, 0xc7, 0x907, 0x147, 0x4c8, 0x8e8, 0x928, 0x548, 0xc9, 0x909, 0x149, 0xea, 0x50a,
+    0x12a, 0x4e6, 0x526, 0x4c7, 0x8e7, 0x927, 0x547, 0x4c9, 0x8e9, 0x929, 0x549, 0x4ea, 0x52a, 0xc6, 0x906, 0x146, 0x8c8, 0x948, 0xca,
+    0x90a, 0x14a, 0x105, 0x4c6, 0x8e6, 0x926, 0x546, 0x8c7, 0x947, 0xa8, 0xd08, 0x168, 0x8c9, 0x949, 0x4ca, 0x8ea, 0x92a, 0x54a,
+    0x10b, 0xe5, 0x505, 0x125, 0xa7, 0xd07, 0x167, 0x4a8, 0xce8, 0xd28, 0x568, 0xa9, 0xd09, 0x169, 0xeb, 0x50b, 0x12b, 0x4e5, 0x525,
+    0x4a7, 0xce7, 0xd27, 0x567, 0x4a9, 0xce9, 0xd29, 0x569, 0x4eb, 0x52b, 0x8c6, 0x946, 0x8ca, 0x94a, 0xc5, 0x905, 0x145, 0xa6, 0xd06,
+    0x166, 0x8a8, 0xcc8, 0xd48, 0x968, 0xaa, 0xd0a, 0x16a, 0xcb, 0x90b, 0x14b, 0x4c5, 0x8e5, 0x925, 0x545, 0x4a6, 0xce6, 0xd26, 0x566,
+    0x8a7, 0xcc7, 0xd47, 0x967, 0x8a9, 0xcc9, 0xd49, 0x969, 0x4aa, 0xcea, 0xd2a, 0x56a, 0x4cb, 0x8eb, 0x92b, 0x54b, 0x104, 0x88,
+    0x1108, 0x188, 0x10c
+};
+__constant__ uint16_t c_vox_near_start[kVoxNear + 2] = {0, 1, 6, 14, 18, 23, 39, 51, 51, 59, 76, 92, 104, 108, 124, 148, 148, 153};
+
 // The occupied cells of every job in cell order, from the occupancy bitmap the build has written: kVoxListWGs workgroups per job,
 // each lists the cells of its segment of the bitmap and counts the bits in front of its segment itself (the whole bitmap is a
 // few thousand words: reading it eight times costs less than a second launch or a hand-off between workgroups).
@@ -186,6 +204,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
     __shared__ uint32_t s_brick[27 * 16];         // occupancy bricks of the 27 cells (zero: empty / outside)
     __shared__ __attribute__((aligned(16))) uint32_t s_rows[576];   // x-rows of the staged 24^3: bit x + 1 of word [Z * 24 + Y]
     __shared__ uint32_t s_dup[16];                // SELF: the cell's own voxels that hold more than one point
+    __shared__ uint16_t s_near[ROWS ? kVoxNearEntries : 1], s_near_start[ROWS ? kVoxNear + 2 : 1];   // ROWS: c_vox_near (lanes index it on their own)
     const QueryJob &J = jobs.j[blockIdx.y];
     const int lane = threadIdx.x;
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
@@ -200,6 +219,10 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
     // what a lane does in every turn, worked out once: its two quarter-bricks of the staging (brick b = t / 4 of 27, cell-start
     // slot r * 4 + k of s_cs) and its three row quads of the transposition
     int st_cs[2], tr_src[3], tr_dst[3];
+    if (ROWS) {
+        for (int k = lane; k < kVoxNearEntries; k += 64) s_near[k] = c_vox_near[k];
+        if (lane < kVoxNear + 2) s_near_start[lane] = c_vox_near_start[lane];
+    }                                             // (the first turn's barriers come before anybody reads them)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int t = lane + 64 * u, b = t >> 2, r = b / 3, k = b - 3 * r;
@@ -313,21 +336,41 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
             }
             if (ROWS) {
                 // ---- 5. the matched row: every voxel at exactly the nearest distance, then the smallest row among their points.
-                //      (a) a second walk over the rows within reach notes the hits -- {dy, dz, dx, side} in 16 bits, nothing else:
+                //      (a) the voxels at exactly d2 are noted as hits -- {dy, dz, dx, side} in 16 bits, nothing else:
                 //      the lanes hit at different rows, and whatever a hit costs is paid by the whole wave at every row;
                 const uint32_t d2 = best >> 8;
-                const bool ok = have && d2 <= 64u;
+                const bool ok = have && d2 <= 64u, close = ok && d2 <= (uint32_t)kVoxNear;
                 uint32_t cnt = 0u;
+                //      near queries (d2 <= kVoxNear: nearly all on decoded content) go through the list of places at exactly d2;
+                {
+                    const int st = close ? (int)s_near_start[d2] : 0, len = close ? (int)s_near_start[d2 + 1u] - st : 0;
+                    for (int i = 0; __ballot(i < len) != 0ull; ++i) {
+                        if (i >= len) continue;
+                        const uint32_t code = s_near[st + i];
+                        const int dz = (int)(code & 0x1fu) - 8, dy = (int)((code >> 5) & 0x1fu) - 8, dx = (int)(code >> 10);
+                        const uint32_t w = s_rows[base + dz * 24 + dy];
+                        if ((w >> (L + dx)) & 1u) {                                   // (L + dx <= 20, L - dx >= 5: never a sentinel bit)
+                            if (cnt < (uint32_t)kVoxTies) s_hit[cnt * 64u + (uint32_t)lane] = (uint16_t)code;
+                            ++cnt;
+                        }
+                        if (dx && ((w >> (L - dx)) & 1u)) {
+                            if (cnt < (uint32_t)kVoxTies) s_hit[cnt * 64u + (uint32_t)lane] = (uint16_t)(code | 0x8000u);
+                            ++cnt;
+                        }
+                    }
+                }
+                //      the others (a wave rarely has one) walk the rows within reach;
+                const bool far = ok && !close;
                 for (int k4 = 0; k4 < kVoxRowsPadded / 4; ++k4) {
                     const uint4 e4 = tab[k4];
-                    if (__ballot(ok && d2 >= (e4.x >> 16)) == 0ull) break;     // (rows are sorted by dy^2 + dz^2: nobody reaches further)
+                    if (__ballot(far && d2 >= (e4.x >> 16)) == 0ull) break;    // (rows are sorted by dy^2 + dz^2: nobody reaches further)
                     const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const uint32_t r2 = ee[u] >> 16;
                         const uint32_t rem = d2 - r2;
                         const uint32_t dx = (uint32_t)(__builtin_sqrtf((float)(int)rem) + 0.5f);
-                        if (!(ok && r2 <= d2 && dx * dx == rem)) continue;        // no voxel of this row lies at exactly d2 from this query
+                        if (!(far && r2 <= d2 && dx * dx == rem)) continue;       // no voxel of this row lies at exactly d2 from this query
                         const int dz = (int)(ee[u] & 0xffu) - 8, dy = (int)((ee[u] >> 8) & 0xffu) - 8;
                         const uint32_t w = s_rows[base + dz * 24 + dy];
                         const uint32_t code = (ee[u] & 0x1fu) | (((ee[u] >> 8) & 0x1fu) << 5) | (dx << 10);   // dz + 8 | (dy + 8) << 5 | dx << 10 (dx <= 8)
