@@ -132,6 +132,7 @@ static void free_cloud(Cloud &c)
     if (c.nrm64) (void)hipFree(c.nrm64);
     if (c.nrm32) (void)hipFree(c.nrm32);
     if (c.rgb64) (void)hipFree(c.rgb64);
+    if (c.rgb8) (void)hipFree(c.rgb8);
     if (c.sp) (void)hipFree(c.sp);
     c.sp = nullptr;
     c.cap_sp = 0;
@@ -141,6 +142,9 @@ static void free_cloud(Cloud &c)
     c.nrm64 = nullptr;
     c.nrm32 = nullptr;
     c.rgb64 = nullptr;
+    c.rgb8 = nullptr;
+    c.cap_rgb8 = 0;
+    c.rgb8_valid = false;
     c.cap32 = c.cap64 = c.cap_nrm = c.cap_nrm32 = c.cap_rgb = 0;
     c.n = c.n_pad = c.n_nrm = c.n_rgb = 0;
 }
@@ -152,6 +156,7 @@ static void drop_cloud(Cloud &c)
     c.nrm_deferred = false;
     c.nrm_host = nullptr;
     c.sp_valid = c.sp_tried = false;
+    c.rgb8_valid = false;
 }
 
 static void free_nn(NNResult &r)
@@ -511,7 +516,15 @@ int pccm_set_colors(pccm_ctx *ctx, int which, const void *rgb, int64_t n, int dt
     PCCM_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(unsigned long long), ctx->stream));
     rc = launch_ingest_normals(ctx, dsrc, dtype, n, c.rgb64, nullptr, stats);      // same widening copy; non-finite values are
     if (rc) return rc;                                                    // allowed here (NumPy propagates them)
+    // colours that are bytes / 255 (nearly all are) also as packed words: Cloud::rgb8
+    c.rgb8_valid = false;
+    if ((rc = grow((void **)&c.rgb8, c.cap_rgb8, (size_t)n * sizeof(uint32_t)))) return rc;
+    PCCM_HIP(hipMemsetAsync(stats + 4, 0, sizeof(unsigned long long), ctx->stream));
+    if ((rc = launch_rgb8(ctx, c, nullptr, (unsigned int *)(stats + 4)))) return rc;
+    unsigned long long not_bytes = 1;
+    PCCM_HIP(hipMemcpyAsync(&not_bytes, stats + 4, sizeof(not_bytes), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    c.rgb8_valid = not_bytes == 0;
     c.n_rgb = n;
     return PCCM_OK;
 }
@@ -535,15 +548,21 @@ int pccm_set_colors_u8(pccm_ctx *ctx, int which, const unsigned char *rgb, int64
     if (rc) return rc;
     rc = launch_colors_from_u8(ctx, (const unsigned char *)dsrc, n * 3, c.rgb64);
     if (rc) return rc;
+    c.rgb8_valid = false;
+    if ((rc = grow((void **)&c.rgb8, c.cap_rgb8, (size_t)n * sizeof(uint32_t)))) return rc;
+    if ((rc = launch_rgb8(ctx, c, (const unsigned char *)dsrc, nullptr))) return rc;
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    c.rgb8_valid = true;
     c.n_rgb = n;
     return PCCM_OK;
 }
 
 // common front end of the two colour calls: operands of direction `dir` and the neighbour rows to use
+// (*drecs: matched records that carry the rows -- the kernel reads the row out of the record, no unpacked copy is made for it)
 static int color_operands(pccm_ctx *ctx, int dir, int scheme, const int32_t *rows, int64_t nrows,
-                          const Cloud **own, const Cloud **other, const int32_t **drows)
+                          const Cloud **own, const Cloud **other, const int32_t **drows, const float4 **drecs)
 {
+    *drecs = nullptr;
     if (dir != PCCM_DIR_LEFT && dir != PCCM_DIR_RIGHT) return fail(PCCM_E_ARG, "colour metrics exist for directions 0 and 1");
     if (scheme < 0 || scheme > 2) return fail(PCCM_E_ARG, "unknown colour scheme %d", scheme);
     const Cloud &it = ctx->cloud[dir == PCCM_DIR_LEFT ? 0 : 1], &se = ctx->cloud[dir == PCCM_DIR_LEFT ? 1 : 0];
@@ -559,9 +578,14 @@ static int color_operands(pccm_ctx *ctx, int dir, int scheme, const int32_t *row
         if (!res.valid) return fail(PCCM_E_STATE, "run pccm_nn for direction %d first", dir);
         if (res.begin != 0 || res.end != it.n)
             return fail(PCCM_E_STATE, "the search of direction %d was sharded: pass the gathered neighbour rows", dir);
-        int rc = ensure_plain(ctx, res);
-        if (rc) return rc;
-        *drows = res.idx;
+        if (!res.plain_valid && res.rec_valid && res.rec_layout == 1 && res.rec_stride == 2 && !res.no_rows) {
+            *drows = nullptr;
+            *drecs = (const float4 *)res.rec.p;
+        } else {
+            int rc = ensure_plain(ctx, res);
+            if (rc) return rc;
+            *drows = res.idx;
+        }
     }
     *own = &it;
     *other = &se;
@@ -576,7 +600,8 @@ int pccm_color_reduce(pccm_ctx *ctx, int dir, int scheme, double scale, const in
     if (!sum_out || !max_out) return fail(PCCM_E_ARG, "null output");
     const Cloud *own[2], *other[2];
     const int32_t *drows[2];
-    int rc = color_operands(ctx, dir, scheme, rows, nrows, &own[0], &other[0], &drows[0]);
+    const float4 *drecs[2];
+    int rc = color_operands(ctx, dir, scheme, rows, nrows, &own[0], &other[0], &drows[0], &drecs[0]);
     if (rc) return rc;
     pccm_ctx::ColorMemo &memo = ctx->color_memo;
     if (!rows && memo.valid && memo.dir == dir && memo.scheme == scheme && memo.scale == scale && memo.gen == ctx->nn_gen[dir] &&
@@ -592,7 +617,7 @@ int pccm_color_reduce(pccm_ctx *ctx, int dir, int scheme, double scale, const in
     int njobs = 1;
     const int sib = dir == PCCM_DIR_LEFT ? PCCM_DIR_RIGHT : PCCM_DIR_LEFT;
     if (!rows && ctx->nn[sib].valid && ctx->nn[sib].begin == 0 && ctx->nn[sib].end == ctx->cloud[sib == PCCM_DIR_LEFT ? 0 : 1].n &&
-        color_operands(ctx, sib, scheme, nullptr, 0, &own[1], &other[1], &drows[1]) == PCCM_OK)
+        color_operands(ctx, sib, scheme, nullptr, 0, &own[1], &other[1], &drows[1], &drecs[1]) == PCCM_OK)
         njobs = 2;
     const int64_t n[2] = {own[0]->n, njobs == 2 ? own[1]->n : 0};
     rc = ensure(ctx, ctx->color_cols, (size_t)(n[0] + n[1]) * 3 * sizeof(double));
@@ -601,13 +626,14 @@ int pccm_color_reduce(pccm_ctx *ctx, int dir, int scheme, double scale, const in
     unsigned long long *small[2] = {(unsigned long long *)ctx->stats.p, (unsigned long long *)ctx->stats.p + 16};
     const double *cols[2] = {(const double *)ctx->color_cols.p, (const double *)ctx->color_cols.p + 3 * n[0]};
     double *sums[2] = {(double *)(small[0] + 3), (double *)(small[1] + 3)};
+    PCCM_HIP(hipMemsetAsync(small[0], 0, (njobs == 2 ? 23 : 7) * sizeof(unsigned long long), ctx->stream));      // (one fill for both jobs' words)
     for (int k = 0; k < njobs; ++k) {
-        PCCM_HIP(hipMemsetAsync(small[k], 0, 7 * sizeof(unsigned long long), ctx->stream));
-        rc = launch_color_rows(ctx, own[k]->rgb64, other[k]->rgb64, drows[k], n[k], other[k]->n, scheme, scale, 4, (double *)cols[k], small[k],
-                               (unsigned int *)(small[k] + 6));
+        const bool bytes = own[k]->rgb8_valid && other[k]->rgb8_valid;
+        rc = launch_color_rows(ctx, own[k]->rgb64, other[k]->rgb64, drows[k], n[k], other[k]->n, scheme, scale, 4, (double *)cols[k], nullptr,
+                               (unsigned int *)(small[k] + 6), bytes ? own[k]->rgb8 : nullptr, bytes ? other[k]->rgb8 : nullptr, drecs[k]);
         if (rc) return rc;
     }
-    rc = launch_color_colsums(ctx, njobs, cols, n, sums);
+    rc = launch_color_colsums(ctx, njobs, cols, n, sums, small);      // (+ the columns' maxima as bit keys into small[k][0..2])
     if (rc) return rc;
     unsigned long long h[2][7];
     for (int k = 0; k < njobs; ++k) PCCM_HIP(hipMemcpyAsync(h[k], small[k], sizeof(h[k]), hipMemcpyDeviceToHost, ctx->stream));
@@ -727,15 +753,17 @@ int pccm_color_rows(pccm_ctx *ctx, int dir, int scheme, double scale, int what, 
     if (what < 0 || what > 3) return fail(PCCM_E_ARG, "what must be 0..3");
     const Cloud *own, *other;
     const int32_t *drows;
-    int rc = color_operands(ctx, dir, scheme, rows, nrows, &own, &other, &drows);
+    const float4 *drecs;
+    int rc = color_operands(ctx, dir, scheme, rows, nrows, &own, &other, &drows, &drecs);
     if (rc) return rc;
     const int64_t n = own->n;
     rc = ensure(ctx, ctx->color_cols, (size_t)n * 3 * sizeof(double));
     if (rc) return rc;
     unsigned long long *small = (unsigned long long *)ctx->stats.p;
     PCCM_HIP(hipMemsetAsync(small + 6, 0, sizeof(unsigned long long), ctx->stream));
+    const bool bytes = own->rgb8_valid && other->rgb8_valid;
     rc = launch_color_rows(ctx, own->rgb64, other->rgb64, drows, n, other->n, scheme, scale, what, (double *)ctx->color_cols.p,
-                           small, (unsigned int *)(small + 6));
+                           small, (unsigned int *)(small + 6), bytes ? own->rgb8 : nullptr, bytes ? other->rgb8 : nullptr, drecs);
     if (rc) return rc;
     unsigned long long flag = 0;
     PCCM_HIP(hipMemcpyAsync(out, ctx->color_cols.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

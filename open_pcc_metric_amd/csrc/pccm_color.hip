@@ -39,24 +39,49 @@ __device__ __forceinline__ unsigned long long max_key(double v)
     return isnan(v) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(v);
 }
 
+// k / 255.0 for every byte k, as the host's and the device's IEEE division give it (the compiler's constant folding is that division)
+struct ByteLut {
+    double v[256];
+    constexpr ByteLut() : v() {
+        for (int k = 0; k < 256; ++k) v[k] = (double)k / 255.0;
+    }
+};
+__constant__ ByteLut c_byte_lut = ByteLut();
+
 // what: 0 own rows in the scheme | 1 neighbour rows in the scheme | 2 scale * (own - other) | 3 its square
 //       (all AoS [n][3] into `out`) | 4 squares as three columns out[c * n + i] + column maxima (bit keys)
+// U8: both clouds' colours are bytes / 255 and come from the packed tables (Cloud::rgb8: 4 bytes per row, the gathered ones out
+//     of the L2) through a 2 KB table of the 256 quotients in LDS -- the same doubles rgb64 holds
+template <bool U8>
 __global__ __launch_bounds__(256) void k_color_rows(const double *__restrict__ own, const double *__restrict__ other,
-                                                    const int32_t *__restrict__ rows, int64_t n, int64_t n_other,
+                                                    const uint32_t *__restrict__ own8, const uint32_t *__restrict__ other8,
+                                                    const int32_t *__restrict__ rows, const float4 *__restrict__ recs, int64_t n, int64_t n_other,
                                                     int scheme, double scale, int what, double *__restrict__ out,
                                                     unsigned long long *__restrict__ maxkeys, unsigned int *__restrict__ bad)
 {
     __shared__ unsigned long long s_max[4][3];
+    __shared__ double s_lut[U8 ? 256 : 1];
+    if (U8) {
+        s_lut[threadIdx.x] = c_byte_lut.v[threadIdx.x];
+        __syncthreads();
+    }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long key[3] = {0ull, 0ull, 0ull};
     if (i < n) {
-        double a[3] = {own[3 * i], own[3 * i + 1], own[3 * i + 2]}, ta[3], tb[3];
-        int64_t r = rows[i];
+        double a[3], b[3], ta[3], tb[3];
+        int64_t r = rows ? rows[i] : (int64_t)__float_as_int(recs[i].w);     // (the matched record carries the row)
         if (r < 0 || r >= n_other) {        // only possible with caller-supplied rows; reported as PCCM_E_RANGE
             atomicOr(bad, 1u);
             r = 0;
         }
-        double b[3] = {other[3 * r], other[3 * r + 1], other[3 * r + 2]};
+        if (U8) {
+            const uint32_t pa = own8[i], pb = other8[r];
+            a[0] = s_lut[pa & 255u]; a[1] = s_lut[(pa >> 8) & 255u]; a[2] = s_lut[(pa >> 16) & 255u];
+            b[0] = s_lut[pb & 255u]; b[1] = s_lut[(pb >> 8) & 255u]; b[2] = s_lut[(pb >> 16) & 255u];
+        } else {
+            a[0] = own[3 * i]; a[1] = own[3 * i + 1]; a[2] = own[3 * i + 2];
+            b[0] = other[3 * r]; b[1] = other[3 * r + 1]; b[2] = other[3 * r + 2];
+        }
         to_scheme(scheme, a, ta);
         to_scheme(scheme, b, tb);
 #pragma unroll
@@ -71,7 +96,7 @@ __global__ __launch_bounds__(256) void k_color_rows(const double *__restrict__ o
             }
         }
     }
-    if (what != 4) return;
+    if (what != 4 || !maxkeys) return;      // (pccm_color_reduce takes the maxima from the column sums' first pass)
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -182,6 +207,7 @@ struct ColsumJob {
     SumSub *groups;            // [3][flag_cap][8]: a flagged sub-chunk's groups of 64 elements, each with a guess of its own
     uint32_t *nflag, *list;    // [3], [3][flag_cap]
     double *out;               // [3]
+    unsigned long long *chunkmax, *outmax;   // [3][nchunks] largest bit key (max_key) of every chunk; [3] of the column, or null
     unsigned long long *dbg;   // DIAG builds: [3][16] stamps and counts of the walk
 };
 struct ColsumJobs {
@@ -199,21 +225,38 @@ __global__ __launch_bounds__(kSumThreads) void k_colsum_approx(ColsumJobs jobs)
     const double *__restrict__ col = J.cols + (int64_t)column * n;
     const int64_t base = (int64_t)blockIdx.x * kSumChunk;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ unsigned long long s_k[kSumWaves];
     if (blockIdx.x == 0 && tid == 0) J.nflag[column] = 0u;      // (the next kernel appends to the column's list)
     double p = 0.0;
+    unsigned long long key = 0ull;                              // the column's maximum rides along (np.max(axis=0): a NaN wins)
 #pragma unroll
     for (int j = 0; j < kSumPer; ++j) {
         const int64_t i = base + (int64_t)j * kSumThreads + tid;
-        p += i < n ? col[i] : 0.0;
+        const double x = i < n ? col[i] : 0.0;
+        p += x;
+        const unsigned long long kx = max_key(x);
+        key = kx > key ? kx : key;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
-    if (lane == 0) s_p[w] = p;
+    for (int off = 32; off > 0; off >>= 1) {
+        p += __shfl_xor(p, off);
+        const unsigned long long o = __shfl_xor(key, off);
+        key = o > key ? o : key;
+    }
+    if (lane == 0) {
+        s_p[w] = p;
+        s_k[w] = key;
+    }
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        for (int k = 0; k < kSumWaves; ++k) t += s_p[k];
+        unsigned long long m = 0ull;
+        for (int k = 0; k < kSumWaves; ++k) {
+            t += s_p[k];
+            m = s_k[k] > m ? s_k[k] : m;
+        }
         J.approx[(int64_t)column * J.nchunks + blockIdx.x] = t;
+        J.chunkmax[(int64_t)column * J.nchunks + blockIdx.x] = m;
     }
 }
 
@@ -449,6 +492,19 @@ __global__ __launch_bounds__(kSumThreads) void k_colsum_chain(ColsumJobs jobs)
     for (int k = tid; k < s_nsub * kSumPer; k += kSumThreads) s_grp[k / kSumPer][k % kSumPer] = J.groups[((int64_t)column * flag_cap + k / kSumPer) * kSumPer + (k % kSumPer)];
     for (int k = tid; k < s_nchunk * kSumWaves; k += kSumThreads) s_sub[k / kSumWaves][k % kSumWaves] = sub[(int64_t)s_cid[k / kSumWaves] * kSumWaves + (k % kSumWaves)];
     __syncthreads();
+    if (w == kSumWaves - 1 && J.outmax) {            // the column's maximum: the last wave, beside the walk
+        unsigned long long m = 0ull;
+        for (int64_t k = lane; k < nchunks; k += 64) {
+            const unsigned long long v = J.chunkmax[(int64_t)column * nchunks + k];
+            m = v > m ? v : m;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(m, off);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) J.outmax[column] = m;
+    }
     if (w != 0) return;
     DG(1, DGT());
     // ---- the walk (one wave).  Every step takes a RUN of records at once (accept_run): as many chunks as fit below the end of
@@ -578,23 +634,61 @@ int launch_colors_from_u8(pccm_ctx *ctx, const unsigned char *src, int64_t n3, d
 
 int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, const int32_t *rows, int64_t n,
                       int64_t n_other, int scheme, double scale, int what, double *out,
-                      unsigned long long *maxkeys, unsigned int *bad)
+                      unsigned long long *maxkeys, unsigned int *bad, const uint32_t *own8, const uint32_t *other8, const float4 *recs)
 {
     ProfScope ps(ctx, PCCM_K_POINT);
-    hipLaunchKernelGGL(k_color_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, own, other, rows, n,
-                       n_other, scheme, scale, what, out, maxkeys, bad);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (own8 && other8)
+        hipLaunchKernelGGL(k_color_rows<true>, grid, dim3(256), 0, ctx->stream, own, other, own8, other8, rows, recs, n, n_other, scheme, scale, what, out,
+                           maxkeys, bad);
+    else
+        hipLaunchKernelGGL(k_color_rows<false>, grid, dim3(256), 0, ctx->stream, own, other, own8, other8, rows, recs, n, n_other, scheme, scale, what, out,
+                           maxkeys, bad);
     PCCM_HIP(hipGetLastError());
     return PCCM_OK;
 }
 
-int launch_color_colsums(pccm_ctx *ctx, int njobs, const double *const cols[2], const int64_t n[2], double *const out3[2])
+// Cloud::rgb8 from the uploaded bytes, or from rgb64 when every value is a byte's quotient (what a reader's k / 255.0 leaves)
+__global__ __launch_bounds__(256) void k_rgb8_pack(const unsigned char *__restrict__ src, const double *__restrict__ rgb64, int64_t n,
+                                                   uint32_t *__restrict__ out, unsigned int *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = 0u;
+    if (src) {
+        p = (uint32_t)src[3 * i] | ((uint32_t)src[3 * i + 1] << 8) | ((uint32_t)src[3 * i + 2] << 16);
+    } else {
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double v = rgb64[3 * i + c];
+            const double k = rint(v * 255.0);
+            const int b = (k >= 0.0 && k <= 255.0) ? (int)k : 0;              // (NaN fails both tests)
+            ok = ok && __double_as_longlong(c_byte_lut.v[b]) == __double_as_longlong(v);
+            p |= (uint32_t)b << (8 * c);
+        }
+        if (!ok) atomicOr(flag, 1u);
+    }
+    out[i] = p;
+}
+
+int launch_rgb8(pccm_ctx *ctx, Cloud &c, const unsigned char *bytes, unsigned int *flag)
+{
+    ProfScope ps(ctx, PCCM_K_INGEST);
+    hipLaunchKernelGGL(k_rgb8_pack, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, ctx->stream, bytes, (const double *)c.rgb64, c.n, c.rgb8, flag);
+    PCCM_HIP(hipGetLastError());
+    return PCCM_OK;
+}
+
+int launch_color_colsums(pccm_ctx *ctx, int njobs, const double *const cols[2], const int64_t n[2], double *const out3[2],
+                         unsigned long long *const outmax[2])
 {
     ProfScope ps(ctx, PCCM_K_REDUCE);
     constexpr int kFlagCap = 64;          // flagged sub-chunks listed per column (the chain stages the first kStageSubs of them)
     // scratch per job: [3][nchunks] approximate chunk sums | [3][nchunks] chunk records | [3][nchunks][16] sub-chunk records |
     //                  [3][kFlagCap][8] group records | counts | lists
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    size_t off[2][6], total = 0;
+    size_t off[2][7], total = 0;
     int64_t nchunks[2] = {0, 0}, most = 0;
     for (int k = 0; k < njobs; ++k) {
         nchunks[k] = (n[k] + kSumChunk - 1) / kSumChunk;
@@ -605,7 +699,8 @@ int launch_color_colsums(pccm_ctx *ctx, int njobs, const double *const cols[2], 
         off[k][3] = off[k][2] + up((size_t)3 * nchunks[k] * kSumWaves * sizeof(SumSub));
         off[k][4] = off[k][3] + up((size_t)3 * kFlagCap * kSumPer * sizeof(SumSub));
         off[k][5] = off[k][4] + 256;
-        total = off[k][5] + up((size_t)3 * kFlagCap * 4);
+        off[k][6] = off[k][5] + up((size_t)3 * kFlagCap * 4);
+        total = off[k][6] + up((size_t)3 * nchunks[k] * sizeof(unsigned long long));
     }
     const size_t o_dbg = total;
     total += 2 * 3 * 16 * sizeof(unsigned long long);
@@ -628,6 +723,8 @@ int launch_color_colsums(pccm_ctx *ctx, int njobs, const double *const cols[2], 
         J.nflag = (uint32_t *)(base + off[s][4]);
         J.list = (uint32_t *)(base + off[s][5]);
         J.out = out3[s];
+        J.chunkmax = (unsigned long long *)(base + off[s][6]);
+        J.outmax = outmax ? outmax[s] : nullptr;
         J.dbg = (unsigned long long *)(base + o_dbg) + s * 48;
     }
     const size_t dyn = (size_t)(kStageSubs + 1) * kSumSub * sizeof(double) + (size_t)kSumMaxChunksLds * sizeof(SumChunk);
@@ -665,7 +762,7 @@ int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *ou
     const double *c[2] = {cols, cols};
     const int64_t nn[2] = {n, n};
     double *o[2] = {out3, out3};
-    return launch_color_colsums(ctx, 1, c, nn, o);
+    return launch_color_colsums(ctx, 1, c, nn, o, nullptr);
 }
 
 }  // namespace pccm

@@ -52,6 +52,11 @@ struct Cloud {
     bool nrm_deferred = false;
     double *rgb64 = nullptr;    // [n_rgb][3] colours as the caller gave them (RGB in [0, 1])
     int64_t n_rgb = 0;
+    // colours that are k / 255.0 for bytes k -- what every file holds -- also live as one packed word per row (r | g << 8 |
+    // b << 16): the colour kernels gather 4 bytes per row from a table the L2 holds instead of 24 from one it does not
+    uint32_t *rgb8 = nullptr;
+    bool rgb8_valid = false;
+    size_t cap_rgb8 = 0;
     // allocations outlive their content (n / n_nrm / n_rgb say what is there): a context that serves one pair after
     // the other -- the engine pool of _native.py -- does not pay hipFree + hipMalloc per cloud
     // the same points in a spatially coherent order (fp32-exact clouds): Rec32 {x, y, z, original row} sorted along a Z-order
@@ -392,11 +397,14 @@ int launch_outside_planes(pccm_ctx *ctx, const double *x64, int64_t n, const dou
                           int32_t *rows_out, unsigned int *count);
 
 // colour columns (pccm_color.hip)
+int launch_rgb8(pccm_ctx *ctx, Cloud &c, const unsigned char *bytes, unsigned int *flag);   // packs Cloud::rgb8 (from bytes, or from rgb64: *flag set when a value is no k / 255.0)
 int launch_color_rows(pccm_ctx *ctx, const double *own, const double *other, const int32_t *rows, int64_t n,
                       int64_t n_other, int scheme, double scale, int what, double *out,
-                      unsigned long long *maxkeys, unsigned int *bad);
+                      unsigned long long *maxkeys, unsigned int *bad, const uint32_t *own8 = nullptr, const uint32_t *other8 = nullptr,
+                      const float4 *recs = nullptr);   // recs: matched records {x, y, z, row} instead of `rows`
 int launch_color_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double *out3);
-int launch_color_colsums(pccm_ctx *ctx, int njobs, const double *const cols[2], const int64_t n[2], double *const out3[2]);
+int launch_color_colsums(pccm_ctx *ctx, int njobs, const double *const cols[2], const int64_t n[2], double *const out3[2],
+                         unsigned long long *const outmax[2]);   // outmax: [3] bit keys of the columns' maxima per job, or null
 int launch_colors_from_u8(pccm_ctx *ctx, const unsigned char *src, int64_t n3, double *out);
 
 }  // namespace pccm
