@@ -205,6 +205,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
     __shared__ __attribute__((aligned(16))) uint32_t s_rows[576];   // x-rows of the staged 24^3: bit x + 1 of word [Z * 24 + Y]
     __shared__ uint32_t s_dup[16];                // SELF: the cell's own voxels that hold more than one point
     __shared__ uint16_t s_near[ROWS ? kVoxNearEntries : 1], s_near_start[ROWS ? kVoxNear + 2 : 1];   // ROWS: c_vox_near (lanes index it on their own)
+    __shared__ __attribute__((aligned(8))) uint16_t s_pre[ROWS ? 27 * 16 : 4];   // ROWS: set bits in front of every word of the 27 bricks (a voxel's rank)
     const QueryJob &J = jobs.j[blockIdx.y];
     const int lane = threadIdx.x;
     const int dimx = g.dim[0], dimy = g.dim[1], dimz = g.dim[2];
@@ -290,6 +291,23 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
                 r[i] = (all << 1) | 0x2000001u;
             }
             *reinterpret_cast<uint4 *>(&s_rows[tr_dst[u]]) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        if (ROWS) {
+            // set bits in front of every brick word: a lane counts a quarter-brick, the quarters in front of it are its quad's
+            // lower lanes (DPP), four 16-bit counts per 8-byte store
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = lane + 64 * u;
+                if (t >= 27 * 4) continue;                // (whole quads: 108 = 27 x 4)
+                const uint4 w = reinterpret_cast<const uint4 *>(s_brick)[t];
+                const uint32_t c0 = (uint32_t)__popc(w.x), c1 = (uint32_t)__popc(w.y), c2 = (uint32_t)__popc(w.z), c3 = (uint32_t)__popc(w.w);
+                const int tot = (int)(c0 + c1 + c2 + c3), part = t & 3;
+                const int q0 = __builtin_amdgcn_update_dpp(0, tot, 0x00, 0xf, 0xf, false), q1 = __builtin_amdgcn_update_dpp(0, tot, 0x55, 0xf, 0xf, false),
+                          q2 = __builtin_amdgcn_update_dpp(0, tot, 0xaa, 0xf, 0xf, false);      // quad_perm: lane 0 / 1 / 2 of the quad
+                const uint32_t b0 = (uint32_t)((part > 0 ? q0 : 0) + (part > 1 ? q1 : 0) + (part > 2 ? q2 : 0));
+                const uint32_t b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2;
+                *reinterpret_cast<uint2 *>(&s_pre[t * 4]) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+            }
         }
         __syncthreads();
         // ---- 4. queries --------------------------------------------------------------------------------------------------
@@ -385,45 +403,39 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
                     }
                 }
                 //      (b) hit j of every lane at once: its voxel, the voxel's rank among the set bits of its cell's brick (the
-                //      sixteen words by four wide reads, v_bcnt with a mask per word), the gather of that voxel's smallest row --
-                //      all gathers of a query in flight together;
-                int rows_of[kVoxTies];
-                uint32_t vox_of[kVoxTies];
-#pragma unroll
-                for (int j = 0; j < kVoxTies; ++j) {
-                    rows_of[j] = 0x7fffffff;
-                    vox_of[j] = 0u;
-                    if ((uint32_t)j < cnt && cnt <= (uint32_t)kVoxTies) {
-                        const uint32_t h = s_hit[j * 64 + lane];
-                        const int dz = (int)(h & 0x1fu) - 8, dy = (int)((h >> 5) & 0x1fu) - 8, dxs = (int)((h >> 10) & 0xfu);
-                        const int X = (h & 0x8000u) ? lx - dxs : lx + dxs, Y = ly + dy, Z = lz + dz;      // 0 .. 23 each
-                        const int rr = (Y >> 3) + 3 * (Z >> 3), bb = rr * 3 + (X >> 3), v = (X & 7) + 8 * (Y & 7) + 64 * (Z & 7);
-                        const uint4 *bw = reinterpret_cast<const uint4 *>(s_brick + bb * 16);
-                        uint32_t rank = 0u;
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const uint4 t = bw[q4];
-                            const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int wv = 4 * q4 + i, sh = v - 32 * wv;                  // bits of word wv below voxel v: all, some or none
-                                const uint32_t m = sh >= 32 ? 0xffffffffu : (sh <= 0 ? 0u : (1u << sh) - 1u);
-                                rank += (uint32_t)__popc(tw[i] & m);
-                            }
-                        }
-                        rows_of[j] = J.vminrow[s_cs[rr * 4 + (X >> 3)] + rank];
-                        vox_of[j] = (uint32_t)X | ((uint32_t)Y << 5) | ((uint32_t)Z << 10);
-                    }
-                }
+                //      bits in front of its word from s_pre + those below it in the word), the gather of that voxel's smallest
+                //      row -- the gathers of a turn in flight together;
+                //      four hits per turn (a query rarely has more): the smallest row so far is all that is carried along;
                 //      (c) the smallest row wins (rows are unique: no tie is left).
                 int wrow = 0x7fffffff;
                 uint32_t wv3 = 0u;
+                const uint32_t usable = cnt <= (uint32_t)kVoxTies ? cnt : 0u;
+                for (int j0 = 0; j0 < kVoxTies; j0 += 4) {
+                    if (__ballot((uint32_t)j0 < usable) == 0ull) break;
+                    int rows_of[4];
+                    uint32_t vox_of[4];
 #pragma unroll
-                for (int j = 0; j < kVoxTies; ++j)
-                    if (rows_of[j] < wrow) {
-                        wrow = rows_of[j];
-                        wv3 = vox_of[j];
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = j0 + jj;
+                        rows_of[jj] = 0x7fffffff;
+                        vox_of[jj] = 0u;
+                        if ((uint32_t)j < usable) {
+                            const uint32_t h = s_hit[j * 64 + lane];
+                            const int dz = (int)(h & 0x1fu) - 8, dy = (int)((h >> 5) & 0x1fu) - 8, dxs = (int)((h >> 10) & 0xfu);
+                            const int X = (h & 0x8000u) ? lx - dxs : lx + dxs, Y = ly + dy, Z = lz + dz;      // 0 .. 23 each
+                            const int rr = (Y >> 3) + 3 * (Z >> 3), bb = rr * 3 + (X >> 3), v = (X & 7) + 8 * (Y & 7) + 64 * (Z & 7);
+                            const uint32_t rank = (uint32_t)s_pre[bb * 16 + (v >> 5)] + (uint32_t)__popc(s_brick[bb * 16 + (v >> 5)] & ((1u << (v & 31)) - 1u));
+                            rows_of[jj] = J.vminrow[s_cs[rr * 4 + (X >> 3)] + rank];
+                            vox_of[jj] = (uint32_t)X | ((uint32_t)Y << 5) | ((uint32_t)Z << 10);
+                        }
                     }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        if (rows_of[jj] < wrow) {
+                            wrow = rows_of[jj];
+                            wv3 = vox_of[jj];
+                        }
+                }
                 if (have) {
                     if (ok && cnt >= 1u && cnt <= (uint32_t)kVoxTies && wrow != 0x7fffffff) {
                         store_result_rec(J.out, __float_as_int(q.w), (float)(rx0 + (int)(wv3 & 31u)), (float)(ry0 + (int)((wv3 >> 5) & 31u)),
