@@ -76,7 +76,7 @@ extern "C" {
 #define PCCM_K_REDUCE 5   /* leaf sums / max / min */
 #define PCCM_K_GRID_BUILD 6
 #define PCCM_K_GRID_QUERY 7  /* k_grid_query_coop: ring 1 of both directions (dominant kernel of PCCM_ENGINE_GRID) */
-#define PCCM_K_GRID_FINISH 8 /* k_grid_finish: rings 2..3 of the unsettled queries */
+#define PCCM_K_GRID_FINISH 8 /* k_grid_tail: rings 2..3 of the unsettled queries + the exact rescan of what they leave */
 #define PCCM_K_COUNT 9
 
 typedef struct pccm_ctx pccm_ctx;

@@ -26,8 +26,8 @@
 //                (thread_search), rings 2..kMaxRing; second half of the same launch: the exact rescan below
 //           surfaces and integer lattices (decide_scale, use_coop):
 //             k_grid_query = thread_search for every query, fp64 throughout
-//           -> k2b_fallback (pccm_brute.hip): exact scan of the whole searched cloud for the queries
-//              kMaxRing rings could not settle (flagged list; its length is read on the device)
+//           -> the exact rescan (pccm_rescan.h; behind the per-thread kernels as k2b_fallback, pccm_brute.hip): scan of the whole
+//              searched cloud for the queries kMaxRing rings could not settle (flagged list; its length is read on the device)
 //
 // Exactness of the stop rule.  cell(x) = clamp(floor((x - org) * inv_h)) is monotonic in x, so a
 // point in a cell left of cell c lies below org + c*h up to a few ulps of the grid's size; the
@@ -116,8 +116,8 @@ __device__ __forceinline__ void scan_range_at(const REC *__restrict__ recs, uint
 }
 
 // A query kMaxRing rings could not settle (isolated outliers, clouds that overlap only in part) goes on the
-// result's flagged list; k2b_fallback (pccm_brute.hip), launched right after this kernel, finds its exact
-// answer by a scan of the whole searched cloud.  Same filter as there: every possible fp64 winner has
+// result's flagged list; the exact rescan (pccm_rescan.h: the second half of k_grid_tail's launch, or k2b_fallback right after a
+// per-thread kernel) finds its exact answer by a scan of the whole searched cloud.  Same filter as there: every possible fp64 winner has
 // d32 <= thr(best found so far).
 __device__ __forceinline__ void defer_rescan(const QueryJob &J, int qrow, double best)
 {

@@ -23,7 +23,7 @@
 //      query's x (v_ffbl / v_ffbh), d2 = dx^2 + dy^2 + dz^2 -- integers: exact, no certification -- until dy^2 + dz^2 reaches
 //      the best d2 so far.
 // A best d2 <= 64 is final: every voxel within 8 of a query of the cell lies inside the staged 24^3.  Anything farther (or
-// nothing found) goes to the tail list and through the general kernels (k_grid_finish -> k2b_fallback), like the brick kernel's.
+// nothing found) goes to the tail list and through the general tail launch (k_grid_tail), like the brick kernel's.
 // Results are matched records {x, y, z of the nearest voxel, its smallest row or -1} (NNOut::layout 1): the reductions form the
 // distance (and the row-indexed projection).
 // Bound: the launch is short and latency-bound (two dependent round trips per wave, thousands of waves in flight); the per-row

@@ -296,8 +296,8 @@ def test_long_runs_inside_the_lds_budget_stay_exact(engine, monkeypatch):
 @pytest.mark.parametrize("margin,note", [(0.012, "several thousand tails: more than one entry per wave at both ends of the wave range"),
                                          (0.05, "tens of thousands: the thread-per-query path")])
 def test_many_tail_queries_stay_exact(engine, monkeypatch, margin, note):
-    """Queries in a rim where the other cloud has no points cannot be settled by ring 1: they go through k_grid_finish
-    (one wave per entry, the two directions' lists handed out from opposite ends) or, past 16384 entries, through the
+    """Queries in a rim where the other cloud has no points cannot be settled by ring 1: they go through k_grid_tail
+    (one wave per entry, the two directions' lists handed out from opposite ends) or, past 2^18 entries, through the
     per-thread search; a few fall through to the exact rescan.  Every row is still the oracle's."""
     rng = np.random.default_rng(31)
     n = 300_000
