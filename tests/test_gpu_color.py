@@ -75,6 +75,15 @@ def test_seq_colsum_one_million_rows(engine):
     assert same_bits(engine.seq_colsum(a), np.add.reduce(a, axis=0))
 
 
+def test_seq_colsum_beyond_the_chunk_records_kept_in_lds(engine):
+    """More than 1536 chunks of 8192 rows: the walk reads the later chunk records from memory."""
+    n = 12_700_000
+    a = _columns("quantised", n, 11)
+    a[:, 1] = _columns("uniform", n, 12)[:, 1] * 1e-3
+    a[n // 2:, 2] = 0.0                                   # a long run of zeros behind the LDS-resident part's end
+    assert same_bits(engine.seq_colsum(a), np.add.reduce(a, axis=0))
+
+
 def test_seq_colsum_zero_columns_take_no_serial_walk(engine):
     """A column of zeros (a pair with identical colours) used to be summed one add after the other: 25 ms per 0.8M rows."""
     import time
