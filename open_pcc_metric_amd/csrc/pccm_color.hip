@@ -327,27 +327,44 @@ __global__ __launch_bounds__(kSumThreads) void k_colsum_units(ColsumJobs jobs)
             // the same once more for each of its eight groups of 64 consecutive elements, every group with the binade the
             // approximate sum in front of IT suggests: the walk then redoes a rejected sub-chunk from eight ready-made totals
             // (and sums only the group a crossing falls into element by element)
+            // (three passes, the eight groups side by side in each: a reduction per group one after the other made the
+            // flagged waves -- and with them their workgroups, and the launch -- 5 us longer)
+            double sg[kSumPer], tg[kSumPer];
+#pragma unroll
+            for (int j = 0; j < kSumPer; ++j) sg[j] = x[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int j = 0; j < kSumPer; ++j) sg[j] += __shfl_xor(sg[j], off);
             double front = start;
+            int eg[kSumPer], fl[kSumPer];
 #pragma unroll
             for (int j = 0; j < kSumPer; ++j) {
                 const Units qg = units_of(front);
                 double k;
                 const bool okg = unit_round(x[j], qg.inv_u, k) && qg.usable;
-                double tg = k, sg = x[j];
+                tg[j] = k;
+                eg[j] = qg.usable ? qg.e : kNoGuess;
+                fl[j] = (__all(okg) ? kRecOk : 0) | (__all(__double_as_longlong(x[j]) == 0ll) ? kRecZero : 0);
+                front += sg[j];
+            }
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    tg += __shfl_xor(tg, off);
-                    sg += __shfl_xor(sg, off);
-                }
-                const int okall = __all(okg), zall = __all(__double_as_longlong(x[j]) == 0ll);
-                if (lane == 0) {
-                    SumSub r;
-                    r.total = zall ? 0.0 : tg;
-                    r.e = qg.usable ? qg.e : kNoGuess;
-                    r.ok = (okall ? kRecOk : 0) | (zall ? kRecZero : 0);
-                    J.groups[((int64_t)column * jobs.flag_cap + pos) * kSumPer + j] = r;
-                }
-                front += sg;
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int j = 0; j < kSumPer; ++j) tg[j] += __shfl_xor(tg[j], off);
+            if (lane < kSumPer) {
+                SumSub r;
+                r.total = 0.0;
+                r.e = kNoGuess;
+                r.ok = 0;
+#pragma unroll
+                for (int j = 0; j < kSumPer; ++j)
+                    if (lane == j) {
+                        r.total = (fl[j] & kRecZero) ? 0.0 : tg[j];
+                        r.e = eg[j];
+                        r.ok = fl[j];
+                    }
+                J.groups[((int64_t)column * jobs.flag_cap + pos) * kSumPer + lane] = r;
             }
         }
     }
