@@ -18,7 +18,7 @@ N > 1   = one process per GPU (torch.distributed, backend nccl = RCCL), the pair
           N_ref = N_deg = 1M at 1/2/4/8 GPUs) -> "scaling": "strong".
 
 Extra records on the same line (N = 1): `full_report` (the step plus the self search behind Min/MaxSqrtDistance,
-which options.py:36-37 always requests), `cold_pair` (a fresh context, nothing inherited), `brute` (the
+which options.py:36-37 always requests), `pair_stream` (two resident pairs taking turns: throughput of a sequence), `cold_pair` (a fresh context, nothing inherited), `brute` (the
 brute-force engine north_star names: k1_scan against the fp32 vector roofline), `end_to_end` (fresh pair incl.
 H2D), `cpu_baseline` / `cpu_reference_pattern` and the same-run parity gate against the oracle.
 """
@@ -559,6 +559,39 @@ def main():
         for _ in range(nwarm):                         # back to the headline report (re-captures its graph)
             result = step()
 
+        # (1a) a STREAM of resident pairs: two pairs in flight on two contexts of the same GPU, the launch of one issued before
+        # the report of the other is made -- what hides the ~50 us the GPU idles between two steps of ONE pair (host wake-up,
+        # the Python behind the last kernel, the next graph launch).  Both pairs are the headline pair (second one: the clouds swapped).
+        with CloudPair(PointCloud(b, nb), PointCloud(a, na), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine,
+                       use_graph=not args.no_graph) as other:
+            def finish(p):
+                return MetricCalculator(p).calculate(headline_metrics()).as_dict()
+            for _ in range(nwarm + 1):
+                pair.recompute(); r0 = finish(pair)
+                other.recompute(); r1 = finish(other)
+            ks = max(20, args.steps)
+            fence()
+            other._engine.sync()
+            t0 = time.perf_counter()
+            pair.recompute()
+            for _ in range(ks):
+                other.recompute()                    # the next pair's launch ...
+                s0 = finish(pair)                    # ... before this pair's report
+                pair.recompute()
+                s1 = finish(other)
+            s0 = finish(pair)
+            other._engine.sync()
+            fence()
+            dts = (time.perf_counter() - t0) / (2 * ks + 1)
+            same = all(s0[k] == r0[k] for k in r0) and all(s1[k] == r1[k] for k in r1)
+            line["pair_stream"] = {"ms_per_pair": round(dts * 1e3, 4), "value": round(2 * n / dts / 1e6, 2), "unit": "Mpoints/s", "pairs": 2 * ks + 1,
+                                   "rows_equal_to_the_single_pair_runs": bool(same),
+                                   "note": "two resident 1M + 1M pairs on two contexts of one GPU, taking turns: each pair's step (grid build, both "
+                                           "sweeps, reductions, report) as in `value`, but the other pair's hipGraph is launched before this pair's "
+                                           "report is read -- throughput of a sequence of pairs, not the latency of one; never `value`"}
+        for _ in range(nwarm):
+            result = step()
+
         # (1b) PCC-like content: voxelised surfaces take the per-thread search, not the brick kernel
         line["content"] = content_record(30)
         line["content_full"] = content_full_record(20)
@@ -582,6 +615,14 @@ def main():
             with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine, _uploads_first=True) as fresh:
                 MetricCalculator(fresh).calculate(headline_metrics()).as_dict()
         dt_serial = (time.perf_counter() - t_ser) / reps
+        # ... and a sequence of fresh pairs through the product's own evaluate_pairs (two host threads, each with a pooled context:
+        # one pair's uploads run beside the other's kernels and report)
+        from open_pcc_metric_amd.sequence import evaluate_pairs
+        seq_items = [(PointCloud(a, na), PointCloud(b, nb)) for _ in range(8)]
+        evaluate_pairs(seq_items[:2], options, device=local, workers=2, extent=[1.0, 1.0, 1.0], nn_engine=args.engine)
+        t_seq = time.perf_counter()
+        seq_rows = evaluate_pairs(seq_items, options, device=local, workers=2, extent=[1.0, 1.0, 1.0], nn_engine=args.engine)
+        dt_seq = (time.perf_counter() - t_seq) / len(seq_items)
         h2d_bytes = a.nbytes + b.nbytes + na.nbytes + nb.nbytes
         # the upload alone, same buffers, same context: what PCIe and the pageable-memory path allow
         ue = nat.Engine(local)
@@ -598,7 +639,8 @@ def main():
         line["end_to_end"] = {"ms_per_pair": round(dt * 1e3, 4), "value": round(2 * n / dt / 1e6, 2), "unit": "Mpoints/s",
                               "h2d_ms": round(up * 1e3, 4), "h2d_bytes": int(h2d_bytes), "h2d_GBs": round(h2d_bytes / up / 1e9, 1),
                               "ms_per_pair_uploads_first": round(dt_serial * 1e3, 4), "hidden_ms": round((dt_serial - dt) * 1e3, 4),
-                              "note": "fresh CloudPair per iteration through the pooled context: H2D of 2 clouds (pageable fp32), ingest, grid "
+                              "ms_per_pair_in_a_sequence": round(dt_seq * 1e3, 4), "sequence_rows_equal": all(r[k] == result[k] for r in seq_rows for k in result if k in r),
+                              "note": "ms_per_pair_in_a_sequence: eight fresh pairs through evaluate_pairs (two host threads with a pooled context each; every row of transform_options(), i.e. with the self search); otherwise: fresh CloudPair per iteration through the pooled context: H2D of 2 clouds (pageable fp32), ingest, grid "
                                       "decisions inherited, both sweeps from the caller's row order (no spatial copy: a pair that is searched "
                                       "once never makes one), the normals' H2D (2 x 12 MB, announced before and flushed behind the sweeps: "
                                       "pccm_set_normals_deferred) on a copy stream beside them, report; h2d_ms = the four uploads + ingests "
