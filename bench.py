@@ -319,6 +319,8 @@ def main():
 
             cli_eng = nat.acquire_engine(local)      # one context for every run below (the pool hands out whichever was released last)
 
+            _kept = []
+
             def run(paths_):
                 st = {"read": 0.0, "upload_and_searches": 0.0, "normals": 0.0, "extent": 0.0, "report": 0.0}
                 t_all = time.perf_counter()
@@ -331,24 +333,34 @@ def main():
                     dec = read_point_cloud(pth)
                     t1 = time.perf_counter()
                     first = pair is None
+                    if os.environ.get("BENCH_CLI_KEEP"):
+                        _kept.append((dec, pair, origin))          # (diagnosis: nothing the runtime may have pinned is given back)
                     if first:
                         cli_eng.reset()
-                        pair = CloudPair(origin, dec, nn_engine=args.engine, normal_index="neighbour", _engine=cli_eng)
+                        pair = CloudPair(origin, dec, nn_engine=args.engine, normal_index="neighbour", _engine=cli_eng, staged_io=True)   # (as handler.py)
                     else:
                         pair = pair.with_reconst(dec)
-                    if first:
+                    skip = os.environ.get("BENCH_CLI_SKIP", "")
+                    if first and "profile" not in skip:
                         pair._engine.profile(True)
                         pair._engine.profile_reset()
                     pair._engine.sync()
                     t2 = time.perf_counter()
-                    pair._require_normals(0)
-                    pair._require_normals(1)
+                    if os.environ.get("BENCH_CLI_DEBUG"):
+                        print("cli pair", len(dec.points), "stage ms", round((t2 - t1) * 1e3, 2), {k: round(pair._engine.profile_get(k)[0] * 1e3, 1) for k in ("grid_build", "grid_query", "grid_finish")},
+                              [pair._engine.nn_stats(d) for d in (0, 1)], file=sys.stderr)
+                    if "normals" not in skip:
+                        pair._require_normals(0)
+                        pair._require_normals(1)
                     pair._engine.sync()
                     t3 = time.perf_counter()
-                    pair.get_extent()
+                    if "extent" not in skip:
+                        pair.get_extent()
                     t4 = time.perf_counter()
-                    with np.errstate(divide="ignore"):
-                        text = MetricCalculator(pair).calculate(transform_options(copts)).as_df().to_string()
+                    text = ""
+                    if "report" not in skip:
+                        with np.errstate(divide="ignore"):
+                            text = MetricCalculator(pair).calculate(transform_options(copts)).as_df().to_string()
                     t5 = time.perf_counter()
                     for key, dtv in (("read", t1 - t0), ("upload_and_searches", t2 - t1), ("normals", t3 - t2), ("extent", t4 - t3), ("report", t5 - t4)):
                         st[key] += dtv

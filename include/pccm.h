@@ -113,6 +113,15 @@ int pccm_set_normals(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int d
 int pccm_set_normals_deferred(pccm_ctx *ctx, int which, const void *nrm, int64_t n, int dtype);
 int pccm_flush_uploads(pccm_ctx *ctx);
 
+/* How arrays of the CALLER cross PCIe (uploads of clouds, normals, colours; downloads of rows, distances, normals ...).
+ * off (default; pccm_ctx_reset restores it): handed to the HIP runtime as they are -- which pins the caller's pages and keeps the
+ * mapping cached: fastest (43 GB/s), but when the caller later FREES such an array the driver evicts and restores every GPU
+ * queue of the process, and a kernel that is running stands still for 13-27 ms (measured).
+ * on: through pinned buffers of the context's own, copied by a few host threads (25 GB/s): for callers that load, use and
+ * free their clouds in a loop (CloudPair.with_reconst, evaluate_pairs with loader items, the command line with several
+ * --pcloud).  No counterpart in the reference. */
+int pccm_set_io_staged(pccm_ctx *ctx, int on);
+
 /* Replaces clouds[k].estimate_normals(), cloud_pair.py:61-64 (Open3D EstimateNormals, default
  * KDTreeSearchParamKNN(knn = 30)): per point, the eigenvector of the smallest eigenvalue of the
  * covariance of its knn nearest points of the same cloud (itself included).  Open3D's own arithmetic

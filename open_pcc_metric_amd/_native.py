@@ -30,7 +30,7 @@ KERNEL_CLASSES = {"ingest": 0, "scan": 1, "refine": 2, "fallback": 3, "point": 4
 # every symbol include/pccm.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "pccm_version", "pccm_last_error", "pccm_device_count", "pccm_ctx_create", "pccm_ctx_destroy", "pccm_ctx_reset",
-    "pccm_set_cloud", "pccm_set_normals", "pccm_set_normals_deferred", "pccm_flush_uploads", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_want_idx", "pccm_nn_fetch",
+    "pccm_set_cloud", "pccm_set_normals", "pccm_set_normals_deferred", "pccm_flush_uploads", "pccm_set_io_staged", "pccm_estimate_normals", "pccm_get_normals", "pccm_set_shard", "pccm_set_shard_dir", "pccm_shard_range", "pccm_nn", "pccm_nn_pair", "pccm_nn_fuse", "pccm_nn_want_idx", "pccm_nn_fetch",
     "pccm_error_vectors", "pccm_point_metric", "pccm_tie_exposure", "pccm_xvec_len", "pccm_reduce_prefetch", "pccm_reduce_prefetch_many", "pccm_reduce", "pccm_finish_sum",
     "pccm_reduce_total", "pccm_reduce_total_many", "pccm_cvec_len", "pccm_reduce_chunks_many", "pccm_finish_chunks",
     "pccm_set_colors", "pccm_set_colors_u8", "pccm_color_reduce", "pccm_color_rows", "pccm_seq_colsum", "pccm_obb_frames", "pccm_extreme_rows", "pccm_rows_outside",
@@ -89,6 +89,7 @@ def load() -> ctypes.CDLL:
     lib.pccm_set_normals.argtypes = [vp, i32, vp, i64, i32, i32]
     lib.pccm_set_normals_deferred.argtypes = [vp, i32, vp, i64, i32]
     lib.pccm_flush_uploads.argtypes = [vp]
+    lib.pccm_set_io_staged.argtypes = [vp, i32]
     lib.pccm_set_shard.argtypes = [vp, i32, i32]
     lib.pccm_set_shard_dir.argtypes = [vp, i32, i32, i32]
     lib.pccm_estimate_normals.argtypes = [vp, i32, i32]
@@ -346,6 +347,11 @@ class Engine:
             return
         _check(self._lib.pccm_set_normals_deferred(self._ctx, int(which), ptr, n, dt))
         self.__dict__.setdefault("_deferred", {})[int(which)] = keep
+
+    def set_io_staged(self, on: bool) -> None:
+        """Large transfers through the context's own pinned buffers (default) or straight from / to the caller's arrays
+        (see pccm_set_io_staged in include/pccm.h)."""
+        _check(self._lib.pccm_set_io_staged(self._ctx, 1 if on else 0))
 
     def flush_uploads(self) -> None:
         try:

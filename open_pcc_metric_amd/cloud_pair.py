@@ -243,7 +243,8 @@ class CloudPair:
     def __init__(self, origin_cloud, reconst_cloud, *, device: typing.Optional[int] = None,
                  nn_engine: str = "auto", normal_index: str = "row", extent=None, group=None,
                  use_graph: bool = False, estimate_normals: bool = True, normals_knn: int = 30,
-                 shard_mode: str = "direction", _engine=None, _uploads_first: bool = False):
+                 shard_mode: str = "direction", _engine=None, _uploads_first: bool = False,
+                 staged_io: typing.Optional[bool] = None):
         if normal_index not in nat.NORMAL_MODES:
             raise ValueError("normal_index must be 'row' or 'neighbour'")
         if nn_engine not in nat.ENGINES:
@@ -269,6 +270,12 @@ class CloudPair:
             self._owns_engine = True
             self._coll.device = device            # the nccl exchange is staged on the same GPU
         self._engine = _engine
+        # ``staged_io``: the clouds' arrays will be FREED while this context is still in use (a sequence of pairs read from files):
+        # their bytes then go through the context's own pinned buffers instead of being handed to the HIP runtime, which pins
+        # the caller's pages and keeps the mapping -- and whose tear-down, when such an array is freed, stops every GPU queue of
+        # the process for 13-27 ms (pccm_set_io_staged).  None: as the context is (direct for a fresh one).
+        if staged_io is not None and hasattr(_engine, "set_io_staged"):
+            _engine.set_io_staged(bool(staged_io))
         self._fast_totals = not self._coll.sharded and hasattr(_engine, "reduce_total")   # whole columns finished by one call
         # Points first; normals are announced and cross PCIe behind the searches, which do not read them (the reference's
         # constructor orders nothing between the two: cloud_pair.py:61-80) -- see the flush at the end
@@ -326,6 +333,8 @@ class CloudPair:
         self.__dict__.pop("_engine")                     # moved: this pair is closed, the context is not handed back
         self._owns_engine = False
         new._engine = eng
+        if hasattr(eng, "set_io_staged"):
+            eng.set_io_staged(True)                              # (the superseded cloud is about to be freed by its owner: see __init__)
         eng.set_cloud(1, reconst_cloud.points)               # (the library keeps cloud 0, everything it owns and its self search)
         deferred = hasattr(eng, "set_normals_deferred")
         if _has_normals(reconst_cloud):

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <new>
+#include <thread>
 
 #include "pccm_internal.h"
 
@@ -201,6 +202,86 @@ static int dir_clouds(pccm_ctx *ctx, int dir, const Cloud **it, const Cloud **se
     return PCCM_OK;
 }
 
+// ---- transfers between caller memory and the device ---------------------------------------------------------------------------
+// A copy on a few host threads (one thread moves ~10 GB/s, the link 50)
+static void host_copy(void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t kPiece = 1u << 20;
+    const int nt = bytes >= 8 * kPiece ? 4 : bytes >= 2 * kPiece ? 2 : 1;
+    if (nt == 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::thread th[3];
+    const size_t part = (bytes / nt + 63) & ~(size_t)63;
+    for (int k = 1; k < nt; ++k) {
+        const size_t off = (size_t)k * part, len = k + 1 < nt ? part : bytes - off;
+        th[k - 1] = std::thread([=] { memcpy((char *)dst + off, (const char *)src + off, len); });
+    }
+    memcpy(dst, src, part);
+    for (int k = 1; k < nt; ++k) th[k - 1].join();
+}
+
+static int pin_ensure(pccm_ctx *ctx, int which, size_t bytes)
+{
+    if (ctx->pin_cap[which] >= bytes) return PCCM_OK;
+    if (ctx->pin[which]) {
+        PCCM_HIP(hipDeviceSynchronize());                       // (a copy out of the old buffer may be in flight)
+        (void)hipHostFree(ctx->pin[which]);
+        ctx->pin[which] = nullptr;
+        ctx->pin_cap[which] = 0;
+    }
+    const size_t cap = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
+    if (hipHostMalloc(&ctx->pin[which], cap, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->pin[which] = nullptr;
+        return fail(PCCM_E_OOM, "hipHostMalloc of %zu bytes (transfer staging) failed", cap);
+    }
+    ctx->pin_cap[which] = cap;
+    return PCCM_OK;
+}
+
+constexpr size_t kStagedFrom = 32u << 10;        // (smaller transfers go through the runtime's own bounce buffers)
+
+// host -> device on stream `st` (the context's main or copy stream)
+static int h2d(pccm_ctx *ctx, void *dev, const void *host, size_t bytes, hipStream_t st)
+{
+    if (!ctx->io_staged || bytes < kStagedFrom) {
+        PCCM_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+        return PCCM_OK;
+    }
+    const int which = st == ctx->stream ? 0 : 1;
+    if (!ctx->pin_ev[which]) PCCM_HIP(hipEventCreateWithFlags(&ctx->pin_ev[which], hipEventDisableTiming));
+    if (ctx->pin_ev_set[which]) PCCM_HIP(hipEventSynchronize(ctx->pin_ev[which]));      // the previous upload has left the buffer
+    int rc = pin_ensure(ctx, which, bytes);
+    if (rc) return rc;
+    constexpr size_t kChunk = 4u << 20;                          // the copy of piece k + 1 runs beside the DMA of piece k
+    for (size_t off = 0; off < bytes; off += kChunk) {
+        const size_t len = bytes - off < kChunk ? bytes - off : kChunk;
+        host_copy((char *)ctx->pin[which] + off, (const char *)host + off, len);
+        PCCM_HIP(hipMemcpyAsync((char *)dev + off, (char *)ctx->pin[which] + off, len, hipMemcpyHostToDevice, st));
+    }
+    PCCM_HIP(hipEventRecord(ctx->pin_ev[which], st));
+    ctx->pin_ev_set[which] = true;
+    return PCCM_OK;
+}
+
+// device -> host on the main stream; the data are in `host` when the call returns only in staged mode -- callers synchronise the
+// stream behind it either way
+static int d2h(pccm_ctx *ctx, void *host, const void *dev, size_t bytes)
+{
+    if (!ctx->io_staged || bytes < kStagedFrom) {
+        PCCM_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return PCCM_OK;
+    }
+    int rc = pin_ensure(ctx, 2, bytes);
+    if (rc) return rc;
+    PCCM_HIP(hipMemcpyAsync(ctx->pin[2], dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    host_copy(host, ctx->pin[2], bytes);
+    return PCCM_OK;
+}
+
 static int upload(pccm_ctx *ctx, const void *src, size_t bytes, int on_device, const void **dev_src)
 {
     if (on_device) {
@@ -209,7 +290,8 @@ static int upload(pccm_ctx *ctx, const void *src, size_t bytes, int on_device, c
     }
     int rc = ensure(ctx, ctx->staging, bytes);
     if (rc) return rc;
-    PCCM_HIP(hipMemcpyAsync(ctx->staging.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = h2d(ctx, ctx->staging.p, src, bytes, ctx->stream);
+    if (rc) return rc;
     *dev_src = ctx->staging.p;
     return PCCM_OK;
 }
@@ -222,7 +304,8 @@ static int ingest_normals(pccm_ctx *ctx, Cloud &c, int which, const void *nrm, i
     if (!on_device) {
         int rc = ensure(ctx, stage, (size_t)n * 3 * esz);
         if (rc) return rc;
-        PCCM_HIP(hipMemcpyAsync(stage.p, nrm, (size_t)n * 3 * esz, hipMemcpyHostToDevice, st));
+        rc = h2d(ctx, stage.p, nrm, (size_t)n * 3 * esz, st);
+        if (rc) return rc;
         dsrc = stage.p;
     }
     unsigned long long *stats = (unsigned long long *)ctx->stats.p + (st == ctx->stream ? 0 : 12);
@@ -374,6 +457,10 @@ int pccm_ctx_destroy(pccm_ctx *ctx)
     }
     grid_release(ctx);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (auto &pbuf : ctx->pin)
+        if (pbuf) (void)hipHostFree(pbuf);
+    for (auto &pe : ctx->pin_ev)
+        if (pe) (void)hipEventDestroy(pe);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PCCM_OK;
@@ -483,6 +570,15 @@ int pccm_set_normals_deferred(pccm_ctx *ctx, int which, const void *nrm, int64_t
     return PCCM_OK;
 }
 
+int pccm_set_io_staged(pccm_ctx *ctx, int on)
+{
+    CHECK_CTX(ctx);
+    NOT_CAPTURING(ctx);
+    PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->io_staged = on != 0;
+    return PCCM_OK;
+}
+
 int pccm_flush_uploads(pccm_ctx *ctx)
 {
     CHECK_CTX(ctx);
@@ -571,7 +667,7 @@ static int color_operands(pccm_ctx *ctx, int dir, int scheme, const int32_t *row
         if (nrows != it.n) return fail(PCCM_E_ARG, "%lld neighbour rows for %lld points", (long long)nrows, (long long)it.n);
         int rc = ensure(ctx, ctx->color_idx, (size_t)nrows * sizeof(int32_t));
         if (rc) return rc;
-        PCCM_HIP(hipMemcpyAsync(ctx->color_idx.p, rows, (size_t)nrows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        { int rch = h2d(ctx, ctx->color_idx.p, rows, (size_t)nrows * sizeof(int32_t), ctx->stream); if (rch) return rch; }
         *drows = (const int32_t *)ctx->color_idx.p;
     } else {
         NNResult &res = ctx->nn[dir];
@@ -665,8 +761,9 @@ int pccm_obb_frames(pccm_ctx *ctx, const double *verts, int64_t nv, const double
     int rc = ensure(ctx, ctx->color_cols, bytes);
     if (rc) return rc;
     double *dv = (double *)ctx->color_cols.p, *dt = dv + 3 * nv, *de = dt + 9 * nt, *dvol = de + 3 * nt;
-    PCCM_HIP(hipMemcpyAsync(dv, verts, (size_t)nv * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    PCCM_HIP(hipMemcpyAsync(dt, tri, (size_t)nt * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // (two uploads through one pinned buffer: the second waits for the first's copy out of it)
+    if ((rc = h2d(ctx, dv, verts, (size_t)nv * 3 * sizeof(double), ctx->stream))) return rc;
+    if ((rc = h2d(ctx, dt, tri, (size_t)nt * 9 * sizeof(double), ctx->stream))) return rc;
     rc = launch_obb_frames(ctx, dv, nv, dt, nt, de, dvol);
     if (rc) return rc;
     std::vector<double> ext((size_t)nt * 3), vol((size_t)nt);
@@ -723,7 +820,10 @@ int pccm_rows_outside(pccm_ctx *ctx, int which, const double *planes, int nplane
     unsigned int hc = 0;
     PCCM_HIP(hipMemcpyAsync(&hc, dcount, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    if (hc) PCCM_HIP(hipMemcpy(rows_out, drows, (size_t)hc * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (hc) {
+        if ((rc = d2h(ctx, rows_out, drows, (size_t)hc * sizeof(int32_t)))) return rc;
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    }
     *count = (int64_t)hc;
     return PCCM_OK;
 }
@@ -735,7 +835,7 @@ int pccm_seq_colsum(pccm_ctx *ctx, const double *cols, int64_t n, double out[3])
     if (!cols || !out || n <= 0) return fail(PCCM_E_ARG, "bad argument");
     int rc = ensure(ctx, ctx->color_cols, (size_t)n * 3 * sizeof(double));
     if (rc) return rc;
-    PCCM_HIP(hipMemcpyAsync(ctx->color_cols.p, cols, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = h2d(ctx, ctx->color_cols.p, cols, (size_t)n * 3 * sizeof(double), ctx->stream))) return rc;
     double *dsum = (double *)ctx->stats.p + 3;
     rc = launch_color_colsum(ctx, (const double *)ctx->color_cols.p, n, dsum);
     if (rc) return rc;
@@ -766,7 +866,7 @@ int pccm_color_rows(pccm_ctx *ctx, int dir, int scheme, double scale, int what, 
                            small, (unsigned int *)(small + 6), bytes ? own->rgb8 : nullptr, bytes ? other->rgb8 : nullptr, drecs);
     if (rc) return rc;
     unsigned long long flag = 0;
-    PCCM_HIP(hipMemcpyAsync(out, ctx->color_cols.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = d2h(ctx, out, ctx->color_cols.p, (size_t)n * 3 * sizeof(double)))) return rc;
     PCCM_HIP(hipMemcpyAsync(&flag, small + 6, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     if (flag) return fail(PCCM_E_RANGE, "a neighbour row is outside the other cloud");
@@ -790,7 +890,7 @@ int pccm_get_normals(pccm_ctx *ctx, int which, double *out)
     Cloud &c = ctx->cloud[which];
     { int rcn = normals_ready(ctx, c); if (rcn) return rcn; }
     if (c.n_nrm <= 0) return fail(PCCM_E_STATE, "cloud %d has no normals", which);
-    PCCM_HIP(hipMemcpyAsync(out, c.nrm64, (size_t)c.n_nrm * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    { int rcd = d2h(ctx, out, c.nrm64, (size_t)c.n_nrm * 3 * sizeof(double)); if (rcd) return rcd; }
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     return PCCM_OK;
 }
@@ -1017,8 +1117,8 @@ int pccm_nn_fetch(pccm_ctx *ctx, int dir, int32_t *idx, double *d2)
     if (rc) return rc;
     if ((rc = ensure_plain(ctx, *res, idx != nullptr))) return rc;
     const int64_t ns = res->end - res->begin;
-    if (ns > 0 && idx) PCCM_HIP(hipMemcpyAsync(idx, res->idx, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (ns > 0 && d2) PCCM_HIP(hipMemcpyAsync(d2, res->d2, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ns > 0 && idx) { int rcd = d2h(ctx, idx, res->idx, (size_t)ns * sizeof(int32_t)); if (rcd) return rcd; }
+    if (ns > 0 && d2) { int rcd = d2h(ctx, d2, res->d2, (size_t)ns * sizeof(double)); if (rcd) return rcd; }
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     return check_device_errors(ctx);
 }
@@ -1056,7 +1156,7 @@ int pccm_error_vectors(pccm_ctx *ctx, int dir, double *out)
     if ((rc = ensure_plain(ctx, *res))) return rc;
     if ((rc = ensure(ctx, ctx->val, (size_t)ns * 3 * sizeof(double)))) return rc;
     if ((rc = launch_point_metric(ctx, *it, *se, *res, PCCM_METRIC_D1, PCCM_NORMAL_ROW, nullptr, (double *)ctx->val.p))) return rc;
-    PCCM_HIP(hipMemcpyAsync(out, ctx->val.p, (size_t)ns * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    { int rcd = d2h(ctx, out, ctx->val.p, (size_t)ns * 3 * sizeof(double)); if (rcd) return rcd; }
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     return PCCM_OK;
 }
@@ -1114,7 +1214,7 @@ int pccm_point_metric(pccm_ctx *ctx, int dir, int metric, int normal_mode, doubl
     NNResult *res;
     int rc = metric_on_device(ctx, dir, metric, normal_mode, &dev, &ns, &it, &res);
     if (rc) return rc;
-    if (ns > 0) PCCM_HIP(hipMemcpyAsync(out, dev, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ns > 0) { int rcd = d2h(ctx, out, dev, (size_t)ns * sizeof(double)); if (rcd) return rcd; }
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
     return PCCM_OK;
 }
@@ -1766,6 +1866,7 @@ int pccm_ctx_reset(pccm_ctx *ctx)
         ctx->cap_ops.clear();
     }
     PCCM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->io_staged = false;                            // (the next owner of the context says what it wants)
     for (int k = 0; k < 2; ++k) {
         drop_cloud(ctx->cloud[k]);
         ctx->cloud[k].version++;

@@ -211,6 +211,15 @@ struct pccm_ctx {
     bool own_stream = false;
     hipStream_t copy_stream = nullptr;     // deferred uploads (pccm_set_normals_deferred): they run beside the main stream's kernels
     pccm::DevBuf staging2;                 // ... through a staging buffer of their own
+    // Large transfers between the CALLER's arrays and the device can go through pinned buffers of the context's own
+    // (pccm_set_io_staged; off by default): the runtime otherwise pins the caller's pages itself and keep the mapping cached, and when the caller later
+    // frees such an array the driver evicts and restores every queue of the process -- 13-27 ms during which a running kernel
+    // stands still (measured: DESIGN.md section 4).  [0]: uploads on the main stream, [1]: on the copy stream, [2]: downloads.
+    void *pin[3] = {nullptr, nullptr, nullptr};
+    size_t pin_cap[3] = {0, 0, 0};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};      // the last upload's copies out of pin[0] / pin[1] have been issued up to here
+    bool pin_ev_set[2] = {false, false};
+    bool io_staged = false;
     pccm::Cloud cloud[2];
     // query-axis shard per direction (pccm_set_shard / pccm_set_shard_dir): this context owns the rows shard_of(n, rank,
     // world) of the iterating cloud; world 0 = none of them (another group of ranks searches that direction)

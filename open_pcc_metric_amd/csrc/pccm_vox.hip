@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64) void k_vox_query(QueryJobs jobs, GridGeom g)
         const int rx0 = gox + 8 * (cx - 1), ry0 = goy + 8 * (cy - 1), rz0 = goz + 8 * (cz - 1);      // voxel (0, 0, 0) of the 24^3
         for (uint32_t qb = 0; qb < nq; qb += 64u) {
             const bool have = qb + (uint32_t)lane < nq;
-            if (qb) q = have ? qrecs[q0 + qb + lane] : q;
+            if (qb && have) q = qrecs[q0 + qb + lane];      // (not `have ? load : q`: a select between the two ADDRESSES puts q -- and the kernel -- into scratch memory)
             // 8 .. 15 by construction (clamped all the same: a shift count or an LDS index must never leave its range -- and a query
             // that does lie outside its cell raises the device error word: the host fails the search instead of reporting it)
             const int ux = (int)q.x - rx0, uy = (int)q.y - ry0, uz = (int)q.z - rz0;

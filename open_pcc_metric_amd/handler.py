@@ -47,8 +47,10 @@ def cli(ocloud, pcloud, color, hausdorff, point_to_plane, csv, device, engine, n
     for path in pcloud:
         pcloud_cloud = read_point_cloud(path)
         if cloud_pair is None:
+            # (clouds read from files are freed while the GPU context works on -- with several decoded clouds, when the next one
+            # is read --: their bytes go through the context's own pinned buffers, see CloudPair's staged_io; 0.6 ms for a pair)
             cloud_pair = CloudPair(ocloud_cloud, pcloud_cloud, device=device, nn_engine=engine, normal_index=normal_index,
-                                   extent=list(extent) if extent else None)
+                                   extent=list(extent) if extent else None, staged_io=True)
         else:
             cloud_pair = cloud_pair.with_reconst(pcloud_cloud)     # the original cloud stays in HBM with all that belongs to it
         calculator = MetricCalculator(cloud_pair)

@@ -48,7 +48,8 @@ def evaluate_pairs(pairs: typing.Iterable[typing.Tuple[typing.Any, typing.Any]],
                 else:
                     if pair is not None:
                         pair.close()
-                    pair = CloudPair(origin, reconst, device=device, **pair_kwargs)
+                    # (items that are LOADED here are freed here, while the context works on: their bytes go through its own buffers)
+                    pair = CloudPair(origin, reconst, device=device, **{"staged_io": callable(item), **pair_kwargs})
                 out[i] = MetricCalculator(pair).calculate(transform_options(options)).as_dict()
                 prev_origin = origin
         finally:
