@@ -36,6 +36,7 @@ out = {"rank": dist.get_rank(), "loaded": loaded,
        "rows": [[[list(map(str, k)), float(v).hex()] for k, v in r.items()] for r in rows]}
 with open(os.path.join(os.environ["PCCM_OUT"], f"rank{dist.get_rank()}.json"), "w") as fh:
     json.dump(out, fh)
+dist.barrier()                      # (orderly teardown: a rank that leaves while a peer's gloo thread still talks to it aborts that peer)
 dist.destroy_process_group()
 '''
 

@@ -60,6 +60,7 @@ out = {"rank": dist.get_rank(), "shard": pair._engine.shard_range(0), "shards": 
        "calls": sorted(set(c[0] for c in pair._engine.calls if c[0].startswith("reduce")))}
 with open(os.path.join(os.environ["PCCM_OUT"], f"rank{dist.get_rank()}.json"), "w") as fh:
     json.dump(out, fh)
+dist.barrier()                      # (orderly teardown: a rank that leaves while a peer's gloo thread still talks to it aborts that peer)
 dist.destroy_process_group()
 '''
 
@@ -139,6 +140,7 @@ except IndexError as exc:
     outcome = "IndexError: " + str(exc)
 with open(os.path.join(os.environ["PCCM_OUT"], f"q1_rank{dist.get_rank()}.json"), "w") as fh:
     json.dump({"rank": dist.get_rank(), "outcome": outcome, "shard": pair._engine.shard_range(0)}, fh)
+dist.barrier()                      # (orderly teardown: a rank that leaves while a peer's gloo thread still talks to it aborts that peer)
 dist.destroy_process_group()
 '''
 
