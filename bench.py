@@ -210,7 +210,8 @@ def main():
         """One step on PCC-like content: both clouds resident, grid build + both sweeps + D1 MSE / PSNR / Hausdorff rows."""
         ca, cb = synth_content()
         copts = CalculateOptions(color=None, hausdorff=True, point_to_plane=False)
-        with CloudPair(PointCloud(ca), PointCloud(cb), extent=[511.0, 322.0, 505.0], device=local, nn_engine=args.engine,
+        # (staged_io: the clouds of this record are freed behind it -- see pccm_set_io_staged; uploads are not in the timed region)
+        with CloudPair(PointCloud(ca), PointCloud(cb), extent=[511.0, 322.0, 505.0], device=local, nn_engine=args.engine, staged_io=True,
                        use_graph=not args.no_graph) as cp:
             ce = cp._engine
 
@@ -258,7 +259,7 @@ def main():
 
         pa, pb = PointCloud(ca, unit(len(ca)), colours(ca) / 255.0), PointCloud(cb, unit(len(cb)), colours(cb) / 255.0)
         copts = CalculateOptions(color="ycc", hausdorff=True, point_to_plane=True)
-        with CloudPair(pa, pb, extent=[511.0, 322.0, 505.0], device=local, nn_engine=args.engine, normal_index="neighbour",
+        with CloudPair(pa, pb, extent=[511.0, 322.0, 505.0], device=local, nn_engine=args.engine, normal_index="neighbour", staged_io=True,
                        use_graph=not args.no_graph) as cp:
             ce = cp._engine
 
