@@ -617,7 +617,7 @@ def main():
         for it in range(reps + 1):                   # the first iteration warms the pooled context and is not counted
             if it == 1:
                 t_e2e = time.perf_counter()
-            with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine) as fresh:
+            with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine, staged_io=False) as fresh:
                 MetricCalculator(fresh).calculate(headline_metrics()).as_dict()
         dt = (time.perf_counter() - t_e2e) / reps
         # ... and with every upload in front of the first search (round 3's order), to see what the new order hides
@@ -625,9 +625,25 @@ def main():
         for it in range(reps + 1):
             if it == 1:
                 t_ser = time.perf_counter()
-            with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine, _uploads_first=True) as fresh:
+            with CloudPair(PointCloud(a, na), PointCloud(b, nb), extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine, _uploads_first=True, staged_io=False) as fresh:
                 MetricCalculator(fresh).calculate(headline_metrics()).as_dict()
         dt_serial = (time.perf_counter() - t_ser) / reps
+        # ... and what a loop over FILES sees: new host arrays for every pair, given back behind it (the copies are not timed).  Direct:
+        # the runtime pins each array; when it is freed the driver evicts and restores the GPU queues, and every other pair stands
+        # still for ~30 ms.  Staged (what CloudPair chooses for a context's second pair on): through the context's own pinned buffers.
+        def fresh_loop(staged, reps=8):
+            out, cl, fp = [], None, None
+            for it in range(reps + 2):
+                # as in `for f in files: cloud = read(f); pair = CloudPair(...)`: the next clouds are made while the previous ones are
+                # still referenced, so they land elsewhere and the previous ones are given back afterwards
+                nxt = (PointCloud(np.array(a), np.array(na)), PointCloud(np.array(b), np.array(nb)))
+                cl = nxt
+                t0 = time.perf_counter()
+                with CloudPair(*cl, extent=[1.0, 1.0, 1.0], device=local, nn_engine=args.engine, staged_io=staged) as fp:
+                    MetricCalculator(fp).calculate(headline_metrics()).as_dict()
+                if it >= 2:
+                    out.append((time.perf_counter() - t0) * 1e3)
+            return out
         # ... and a sequence of fresh pairs through the product's own evaluate_pairs (two host threads, each with a pooled context:
         # one pair's uploads run beside the other's kernels and report)
         from open_pcc_metric_amd.sequence import evaluate_pairs
@@ -646,14 +662,18 @@ def main():
         ue.sync()
         up = (time.perf_counter() - t_up) / reps
         ue.close()
+        fresh_staged, fresh_direct = fresh_loop(True), fresh_loop(False)      # (last: the direct loop leaves mappings behind whose tear-down disturbs whatever runs next)
         # the same fresh pair with the points alone uploaded before the searches start (the round-3 order for comparison is gone:
         # CloudPair announces normals and flushes them behind the sweeps); what a resident pair costs for the same work once,
         # eagerly (no graph), is the non-PCIe share
         line["end_to_end"] = {"ms_per_pair": round(dt * 1e3, 4), "value": round(2 * n / dt / 1e6, 2), "unit": "Mpoints/s",
                               "h2d_ms": round(up * 1e3, 4), "h2d_bytes": int(h2d_bytes), "h2d_GBs": round(h2d_bytes / up / 1e9, 1),
                               "ms_per_pair_uploads_first": round(dt_serial * 1e3, 4), "hidden_ms": round((dt_serial - dt) * 1e3, 4),
+                              "fresh_arrays_ms_per_pair": {"direct": [round(x, 2) for x in fresh_direct], "staged": [round(x, 2) for x in fresh_staged],
+                                                           "mean_direct": round(sum(fresh_direct) / len(fresh_direct), 2),
+                                                           "mean_staged": round(sum(fresh_staged) / len(fresh_staged), 2)},
                               "ms_per_pair_in_a_sequence": round(dt_seq * 1e3, 4), "sequence_rows_equal": all(r[k] == result[k] for r in seq_rows for k in result if k in r),
-                              "note": "ms_per_pair_in_a_sequence: eight fresh pairs through evaluate_pairs (two host threads with a pooled context each; every row of transform_options(), i.e. with the self search); otherwise: fresh CloudPair per iteration through the pooled context: H2D of 2 clouds (pageable fp32), ingest, grid "
+                              "note": "ms_per_pair etc.: the SAME host arrays every iteration, handed to the runtime as they are (staged_io=False): what rounds 1-3 measured; fresh_arrays_ms_per_pair: new arrays per pair, freed behind it; ms_per_pair_in_a_sequence: eight fresh pairs through evaluate_pairs (two host threads with a pooled context each; every row of transform_options(), i.e. with the self search); otherwise: fresh CloudPair per iteration through the pooled context: H2D of 2 clouds (pageable fp32), ingest, grid "
                                       "decisions inherited, both sweeps from the caller's row order (no spatial copy: a pair that is searched "
                                       "once never makes one), the normals' H2D (2 x 12 MB, announced before and flushed behind the sweeps: "
                                       "pccm_set_normals_deferred) on a copy stream beside them, report; h2d_ms = the four uploads + ingests "

@@ -232,6 +232,7 @@ def acquire_engine(device: int = 0) -> "Engine":
             return Engine(device)
         try:
             eng.reset()
+            eng.pairs_served = getattr(eng, "pairs_served", 0) + 1      # (a context on its second pair: a loop over pairs, see CloudPair)
             return eng
         except PccmStateError:                 # a context that cannot be reset is not worth keeping
             eng.close()

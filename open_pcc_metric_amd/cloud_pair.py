@@ -273,7 +273,12 @@ class CloudPair:
         # ``staged_io``: the clouds' arrays will be FREED while this context is still in use (a sequence of pairs read from files):
         # their bytes then go through the context's own pinned buffers instead of being handed to the HIP runtime, which pins
         # the caller's pages and keeps the mapping -- and whose tear-down, when such an array is freed, stops every GPU queue of
-        # the process for 13-27 ms (pccm_set_io_staged).  None: as the context is (direct for a fresh one).
+        # the process for 13-27 ms (pccm_set_io_staged).  None: direct for a context's first pair, staged from its second on.
+        # A pooled context that has served a pair before means a LOOP over pairs -- whose clouds are normally read, used and
+        # freed one after the other -- and takes the staged path unless told otherwise (a loop over fresh 1M-point pairs: 2.2-5 ms
+        # per pair staged; direct, every second pair stands still for 30 ms).
+        if staged_io is None and self._owns_engine and getattr(_engine, "pairs_served", 0) >= 1:
+            staged_io = True
         if staged_io is not None and hasattr(_engine, "set_io_staged"):
             _engine.set_io_staged(bool(staged_io))
         self._fast_totals = not self._coll.sharded and hasattr(_engine, "reduce_total")   # whole columns finished by one call
