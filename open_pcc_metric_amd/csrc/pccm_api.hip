@@ -242,6 +242,7 @@ static int pin_ensure(pccm_ctx *ctx, int which, size_t bytes)
 }
 
 constexpr size_t kStagedFrom = 32u << 10;        // (smaller transfers go through the runtime's own bounce buffers)
+constexpr size_t kPinWindow = 64u << 20;         // most pinned memory one of the three buffers holds: larger transfers reuse it window by window
 
 // host -> device on stream `st` (the context's main or copy stream)
 static int h2d(pccm_ctx *ctx, void *dev, const void *host, size_t bytes, hipStream_t st)
@@ -253,13 +254,18 @@ static int h2d(pccm_ctx *ctx, void *dev, const void *host, size_t bytes, hipStre
     const int which = st == ctx->stream ? 0 : 1;
     if (!ctx->pin_ev[which]) PCCM_HIP(hipEventCreateWithFlags(&ctx->pin_ev[which], hipEventDisableTiming));
     if (ctx->pin_ev_set[which]) PCCM_HIP(hipEventSynchronize(ctx->pin_ev[which]));      // the previous upload has left the buffer
-    int rc = pin_ensure(ctx, which, bytes);
+    int rc = pin_ensure(ctx, which, bytes < kPinWindow ? bytes : kPinWindow);
     if (rc) return rc;
     constexpr size_t kChunk = 4u << 20;                          // the copy of piece k + 1 runs beside the DMA of piece k
+    static_assert(kPinWindow % kChunk == 0, "whole pieces per window");
     for (size_t off = 0; off < bytes; off += kChunk) {
-        const size_t len = bytes - off < kChunk ? bytes - off : kChunk;
-        host_copy((char *)ctx->pin[which] + off, (const char *)host + off, len);
-        PCCM_HIP(hipMemcpyAsync((char *)dev + off, (char *)ctx->pin[which] + off, len, hipMemcpyHostToDevice, st));
+        const size_t len = bytes - off < kChunk ? bytes - off : kChunk, at = off % kPinWindow;
+        if (off && at == 0) {                                    // the window is full: its pieces must have left before it is refilled
+            PCCM_HIP(hipEventRecord(ctx->pin_ev[which], st));
+            PCCM_HIP(hipEventSynchronize(ctx->pin_ev[which]));
+        }
+        host_copy((char *)ctx->pin[which] + at, (const char *)host + off, len);
+        PCCM_HIP(hipMemcpyAsync((char *)dev + off, (char *)ctx->pin[which] + at, len, hipMemcpyHostToDevice, st));
     }
     PCCM_HIP(hipEventRecord(ctx->pin_ev[which], st));
     ctx->pin_ev_set[which] = true;
@@ -274,11 +280,14 @@ static int d2h(pccm_ctx *ctx, void *host, const void *dev, size_t bytes)
         PCCM_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
         return PCCM_OK;
     }
-    int rc = pin_ensure(ctx, 2, bytes);
+    int rc = pin_ensure(ctx, 2, bytes < kPinWindow ? bytes : kPinWindow);
     if (rc) return rc;
-    PCCM_HIP(hipMemcpyAsync(ctx->pin[2], dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PCCM_HIP(hipStreamSynchronize(ctx->stream));
-    host_copy(host, ctx->pin[2], bytes);
+    for (size_t off = 0; off < bytes; off += kPinWindow) {
+        const size_t len = bytes - off < kPinWindow ? bytes - off : kPinWindow;
+        PCCM_HIP(hipMemcpyAsync(ctx->pin[2], (const char *)dev + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        PCCM_HIP(hipStreamSynchronize(ctx->stream));
+        host_copy((char *)host + off, ctx->pin[2], len);
+    }
     return PCCM_OK;
 }
 

@@ -215,7 +215,7 @@ struct pccm_ctx {
     // (pccm_set_io_staged; off by default): the runtime otherwise pins the caller's pages itself and keep the mapping cached, and when the caller later
     // frees such an array the driver evicts and restores every queue of the process -- 13-27 ms during which a running kernel
     // stands still (measured: DESIGN.md section 4).  [0]: uploads on the main stream, [1]: on the copy stream, [2]: downloads.
-    void *pin[3] = {nullptr, nullptr, nullptr};
+    void *pin[3] = {nullptr, nullptr, nullptr};      // (at most 64 MB each: larger transfers reuse the buffer window by window)
     size_t pin_cap[3] = {0, 0, 0};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};      // the last upload's copies out of pin[0] / pin[1] have been issued up to here
     bool pin_ev_set[2] = {false, false};

@@ -46,3 +46,22 @@ def test_staged_transfers_carry_the_same_bytes(dtype):
     for k in direct:
         assert same_bits(direct[k], staged[k]), k
         assert same_bits(direct[k], again[k]), k
+
+
+def test_staged_transfers_larger_than_the_pinned_window():
+    """More than 64 MB per transfer: the pinned buffer is reused window by window, in both directions."""
+    n = 3_200_000                                                # 76.8 MB of fp64 points, normals and error vectors each
+    rng = np.random.default_rng(5)
+    a = rng.random((n, 3))
+    b = a[::-1].copy()
+    nb = unit_normals(n, 7).astype(np.float64)
+    e = nat.Engine(0)
+    e.set_io_staged(True)
+    e.set_cloud(0, a)
+    e.set_cloud(1, b)
+    e.set_normals(1, nb)
+    assert same_bits(e.get_normals(1), nb)                       # up through two windows, down through two windows
+    e.nn(nat.DIR_LEFT, "grid")
+    idx, d2 = e.fetch_nn(nat.DIR_LEFT)
+    assert np.array_equal(idx, np.arange(n)[::-1]) and not d2.any()
+    e.close()
